@@ -1,0 +1,135 @@
+"""Oracle: CNN x3 -> 2-layer BiGRU -> attention pool -> Linear, functional fp32 (CPU).
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).  PINNED against the
+reference's own ``CNNAudioGRU`` by ``tests/golden/model_golden.npz``.
+
+A from-scratch restatement over a plain ``state_dict`` -- explicit BatchNorm and an
+explicit GRU cell loop instead of ``nn.BatchNorm2d`` / ``nn.GRU`` -- of
+  /root/reference/models/models.py:41-68   (forward)
+  /root/reference/models/models.py:10-39   (layer shapes / state_dict keys)
+  /root/reference/scripts/train.py:104-107 (CE loss, backward, optimiser step)
+  /root/reference/scripts/train.py:246-250 (Adam with coupled L2 weight decay)
+Gradients come from torch autograd over this functional forward (plain PyTorch
+fp32), which is the reference's own backward on CPU.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+HIDDEN = 256
+
+PARAM_KEYS = (
+    ["conv1.weight", "bn1.weight", "bn1.bias", "conv2.weight", "bn2.weight", "bn2.bias",
+     "conv3.weight", "bn3.weight", "bn3.bias"]
+    + [f"gru.{n}_l{l}{s}" for l in (0, 1) for s in ("", "_reverse")
+       for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    + ["attention.weight", "attention.bias", "fc.weight", "fc.bias"]
+)
+
+
+def _bn(x, sd, i, train, new_stats=None):
+    g, b = sd[f"bn{i}.weight"], sd[f"bn{i}.bias"]
+    if train:
+        mean = x.mean(dim=(0, 2, 3))
+        var_b = x.var(dim=(0, 2, 3), unbiased=False)
+        if new_stats is not None:
+            n = x.numel() // x.shape[1]
+            var_u = var_b * (n / (n - 1))
+            new_stats[f"bn{i}.running_mean"] = ((1 - BN_MOMENTUM) * sd[f"bn{i}.running_mean"]
+                                                + BN_MOMENTUM * mean).detach()
+            new_stats[f"bn{i}.running_var"] = ((1 - BN_MOMENTUM) * sd[f"bn{i}.running_var"]
+                                               + BN_MOMENTUM * var_u).detach()
+    else:
+        mean, var_b = sd[f"bn{i}.running_mean"], sd[f"bn{i}.running_var"]
+    inv = torch.rsqrt(var_b + BN_EPS)
+    return (x - mean[None, :, None, None]) * (inv * g)[None, :, None, None] + b[None, :, None, None]
+
+
+def cnn_stack(x, sd, train=False, new_stats=None):
+    """x [B,1,H,W] -> [B,128,H/8,W/8]  (models.py:50-52)."""
+    for i in (1, 2, 3):
+        x = F.conv2d(x, sd[f"conv{i}.weight"], bias=None, stride=1, padding=1)
+        x = _bn(x, sd, i, train, new_stats)
+        x = F.max_pool2d(torch.relu(x), 2)
+    return x
+
+
+def gru_direction(x, w_ih, w_hh, b_ih, b_hh, reverse):
+    """x [B,T,I] -> [B,T,H]; gate order r,z,n; h0 = 0 (torch.nn.GRU semantics)."""
+    bsz, steps, _ = x.shape
+    gi = x @ w_ih.t() + b_ih
+    h = x.new_zeros(bsz, HIDDEN)
+    outs = [None] * steps
+    order = range(steps - 1, -1, -1) if reverse else range(steps)
+    for t in order:
+        gh = h @ w_hh.t() + b_hh
+        i_r, i_z, i_n = gi[:, t].chunk(3, dim=1)
+        h_r, h_z, h_n = gh.chunk(3, dim=1)
+        r = torch.sigmoid(i_r + h_r)
+        z = torch.sigmoid(i_z + h_z)
+        n = torch.tanh(i_n + r * h_n)
+        h = (1.0 - z) * n + z * h
+        outs[t] = h
+    return torch.stack(outs, dim=1)
+
+
+def bigru(x, sd, dropout_mask=None):
+    """2-layer bidirectional GRU, batch_first.  ``dropout_mask`` ([B,T,512], already scaled
+    by 1/(1-p)) stands for the inter-layer dropout of models.py:32; None = no dropout."""
+    for layer in (0, 1):
+        fwd = gru_direction(x, sd[f"gru.weight_ih_l{layer}"], sd[f"gru.weight_hh_l{layer}"],
+                            sd[f"gru.bias_ih_l{layer}"], sd[f"gru.bias_hh_l{layer}"], False)
+        rev = gru_direction(x, sd[f"gru.weight_ih_l{layer}_reverse"], sd[f"gru.weight_hh_l{layer}_reverse"],
+                            sd[f"gru.bias_ih_l{layer}_reverse"], sd[f"gru.bias_hh_l{layer}_reverse"], True)
+        x = torch.cat([fwd, rev], dim=2)
+        if layer == 0 and dropout_mask is not None:
+            x = x * dropout_mask
+    return x
+
+
+def forward(sd, x, train=False, new_stats=None, dropout_mask=None, stages=None):
+    """x [B,64,T] or [B,1,64,T] -> logits [B,C]  (models.py:41-68)."""
+    if x.dim() == 3:
+        x = x.unsqueeze(1)
+    x = cnn_stack(x, sd, train, new_stats)
+    b, c, h, w = x.shape
+    seq = x.permute(0, 3, 1, 2).contiguous().view(b, w, c * h)     # feature = c*h_dim + h
+    if stages is not None:
+        stages["gru_in"] = seq
+    y = bigru(seq, sd, dropout_mask)
+    if stages is not None:
+        stages["gru_out"] = y
+    scores = y @ sd["attention.weight"].t() + sd["attention.bias"]  # [B,T,1]
+    attn = torch.softmax(scores, dim=1)
+    ctx = (y * attn).sum(dim=1)
+    if stages is not None:
+        stages["ctx"] = ctx
+    return ctx @ sd["fc.weight"].t() + sd["fc.bias"]
+
+
+def loss_and_grads(sd, x, labels, dropout_mask=None):
+    """One training-mode forward/backward (CE mean).  Returns loss, grads{key}, new BN stats, logits."""
+    params = {k: sd[k].detach().clone().requires_grad_(True) for k in PARAM_KEYS}
+    full = dict(sd)
+    full.update(params)
+    new_stats = {}
+    logits = forward(full, x, train=True, new_stats=new_stats, dropout_mask=dropout_mask)
+    loss = F.cross_entropy(logits, labels)
+    grads = torch.autograd.grad(loss, [params[k] for k in PARAM_KEYS])
+    return loss.detach(), dict(zip(PARAM_KEYS, grads)), new_stats, logits.detach()
+
+
+def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """torch.optim.Adam (non-AMSGrad, coupled L2) single-tensor update; returns (p, m, v)."""
+    if weight_decay != 0.0:
+        g = g + weight_decay * p
+    m = beta1 * m + (1.0 - beta1) * g
+    v = beta2 * v + (1.0 - beta2) * g * g
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    denom = v.sqrt() / math.sqrt(bc2) + eps
+    p = p - (lr / bc1) * (m / denom)
+    return p, m, v

@@ -1,0 +1,110 @@
+"""CPU: pin the oracle.  model_ref vs outputs of the reference's own CNNAudioGRU
+(tests/golden/model_golden.npz); features_ref f32 vs its committed outputs and vs the
+independent float64 path / transformers' mel filter bank (parity for features is
+unpinned by the reference -- see oracle/__init__.py)."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import features_ref, model_ref
+from sir_amd import synth
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return synth.synth_state_dict(31, seed=0)
+
+
+def test_model_eval_matches_reference(sd, model_golden):
+    inp = cases.model_inputs()
+    with torch.no_grad():
+        lg8 = model_ref.forward(sd, inp["x_eval8"])
+        lg1 = model_ref.forward(sd, inp["x_eval1_t94"])
+    np.testing.assert_allclose(lg8.numpy(), model_golden["eval8_logits"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(lg1.numpy(), model_golden["eval1_logits"], rtol=0, atol=2e-6)
+    assert (lg8.argmax(1).numpy() == model_golden["eval8_argmax"]).all()
+    assert (lg1.argmax(1).numpy() == model_golden["eval1_argmax"]).all()
+
+
+def test_model_sharp_head_argmax_matches_reference(sd, model_golden):
+    inp = cases.model_inputs()
+    sds = cases.sharp_head(sd, model_golden["sharp_fc_bias"])
+    with torch.no_grad():
+        lg = model_ref.forward(sds, inp["x_sharp64"])
+    np.testing.assert_allclose(lg.numpy(), model_golden["sharp64_logits"], rtol=0, atol=1e-4)
+    assert (lg.argmax(1).numpy() == model_golden["sharp64_argmax"]).all()
+    assert len(set(model_golden["sharp64_argmax"].tolist())) >= 8     # the case is discriminating
+
+
+def test_model_train_step_matches_reference(sd, model_golden):
+    inp = cases.model_inputs()
+    loss, grads, new_stats, logits = model_ref.loss_and_grads(sd, inp["x_train8"], inp["y_train8"])
+    assert abs(loss.item() - float(model_golden["train8_loss"])) < 2e-6
+    np.testing.assert_allclose(logits.numpy(), model_golden["train8_logits"], rtol=0, atol=2e-6)
+    for k in model_ref.PARAM_KEYS:
+        g = grads[k].flatten()
+        idx = cases.sample_indices(k, g.numel())
+        ref = model_golden[f"grad_samp/{k}"]
+        scale = max(float(model_golden[f"grad_norm/{k}"]) / np.sqrt(g.numel()), 1e-12)
+        # attention.bias has an analytically zero gradient (softmax shift invariance): absolute floor
+        assert np.abs(g[idx].numpy() - ref).max() <= 2e-4 * scale + 5e-8, k
+        assert abs(g.double().norm().item() - float(model_golden[f"grad_norm/{k}"])) <= 1e-4 * float(
+            model_golden[f"grad_norm/{k}"]) + 5e-8, k
+        p, m, v = model_ref.adam_step(sd[k], grads[k], torch.zeros_like(sd[k]), torch.zeros_like(sd[k]),
+                                      step=1, lr=cases.LR, weight_decay=cases.WEIGHT_DECAY)
+        np.testing.assert_allclose(p.flatten()[idx].numpy(), model_golden[f"adam_samp/{k}"], rtol=0, atol=2e-7,
+                                   err_msg=k)
+    for i in (1, 2, 3):
+        np.testing.assert_allclose(new_stats[f"bn{i}.running_mean"].numpy(), model_golden[f"bn{i}.running_mean"],
+                                   rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(new_stats[f"bn{i}.running_var"].numpy(), model_golden[f"bn{i}.running_var"],
+                                   rtol=1e-5, atol=1e-6)
+
+
+def test_features_f32_reproduce_committed(features_golden):
+    for name, wave in cases.feature_cases().items():
+        st = features_ref.extract_features_f32(wave, stages=True)
+        np.testing.assert_allclose(st["db"].numpy(), features_golden[f"{name}/db"], rtol=0, atol=2e-4, err_msg=name)
+        np.testing.assert_allclose(features_ref.pad_or_trim(st["norm"]).numpy(), features_golden[f"{name}/padded"],
+                                   rtol=0, atol=2e-5, err_msg=name)
+
+
+def test_features_f32_vs_f64():
+    """float32 torch.stft path vs independent float64 numpy path: |a-b| <= 1e-4*max(1,|b|) on dB
+    for ordinary clips (tolerance definition)."""
+    cs = cases.feature_cases()
+    for name in ("clip0", "clip1", "half_silent", "len_47999", "len_700", "len_90000"):
+        a = features_ref.extract_features_f32(cs[name], stages=True)
+        b = features_ref.extract_features_f64(cs[name].numpy(), stages=True)
+        db_a, db_b = a["db"].numpy().astype(np.float64), b["db"]
+        assert db_a.shape == db_b.shape
+        assert (np.abs(db_a - db_b) <= 2e-4 * np.maximum(1.0, np.abs(db_b))).all(), name
+        assert np.abs(a["norm"].numpy() - b["norm"]).max() < 2e-4, name
+
+
+def test_features_edge_cases():
+    cs = cases.feature_cases()
+    sil = features_ref.extract_features_f32(cs["silence"], stages=True)
+    assert (sil["db"] == -100.0).all()           # 1e-10 clamp is exact
+    assert (sil["norm"] == 0.0).all()            # 0 / (0 + 1e-5)
+    assert features_ref.extract_features_f32(torch.zeros(512)) is None     # reflect pad needs L > 512
+    assert features_ref.extract_features_f32(cs["len_700"]).shape == (64, 2)
+    assert features_ref.extract_features_f32(cs["len_90000"]).shape == (64, 157)   # truncated to 5 s
+    assert features_ref.extract_features_f32(cs["clip0"]).shape == (64, 94)
+    assert features_ref.pad_or_trim(features_ref.extract_features_f32(cs["clip0"])).shape == (64, 200)
+
+
+def test_fbank_vs_transformers_and_f64():
+    fb32 = features_ref.mel_fbank_f32().numpy()
+    fb64 = features_ref.mel_fbank_f64()
+    assert np.abs(fb32 - fb64).max() < 2e-5
+    assert (fb32 > 0).sum() <= 1100 and fb32.shape == (513, 64)
+    tf = pytest.importorskip("transformers.audio_utils")
+    ref = tf.mel_filter_bank(513, 64, 0.0, 8000.0, 16000, norm=None, mel_scale="htk")
+    assert np.abs(fb32 - ref).max() < 2e-5
+
+
+def test_frame_counts():
+    for n, t in ((16000, 32), (48000, 94), (80000, 157), (513, 2), (47999, 94)):
+        assert features_ref.num_frames(n) == t
