@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: batched audio -> intent inference on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of 256 synthetic 16 kHz / 3 s clips that
+are already resident in HBM: fused HIP feature extraction (framed rFFT -> mel -> log -> z-norm ->
+pad to 200 frames) followed by the HIP CNN/BiGRU/attention forward and argmax -- BASELINE.json
+configs[1].  Utterances are independent, so N > 1 shards them (one process per GPU, 256 per GPU
+per step, weak scaling) with no collective on the data path; torch.distributed (RCCL) is used only
+for the barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  roofline     -- dominant kernel, achieved vs peak, timed live with HIP events on its stream
+  cpu_baseline -- the CPU restatement of the reference path (oracle/, "port") timed on the host
+                  cores of this box on a bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+BATCH = 256
+CLIP_LEN = 48000
+T_PAD = 200
+NUM_CLASSES = 31
+N_POOL = 8                       # distinct batches staged in HBM (8 x 49 MB > the 256 MB MALL)
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
+
+# algorithmic work per utterance at T = 200 frames
+FLOPS_PER_UTT = {
+    "conv1_bn_relu_pool": 2 * 32 * 9 * 64 * 200,
+    "conv2_mfma_bn_relu_pool": 2 * 64 * 288 * 32 * 100,
+    "conv3_mfma_bn_relu_pool": 2 * 128 * 576 * 16 * 50,
+    "gemm_ih_l0": 2 * 25 * 1024 * 1536,
+    "gemm_ih_l1": 2 * 25 * 512 * 1536,
+    "gru_recurrence_l0": 2 * 25 * 2 * 768 * 256,
+    "gru_recurrence_l1": 2 * 25 * 2 * 768 * 256,
+}
+FEATURE_BYTES_PER_UTT = CLIP_LEN * 4 + 64 * T_PAD * 4       # 243 200 B (fp32 waveform in, features out)
+
+
+def device_clips(n, length, seed, device):
+    """Synthetic clips generated on the device: 0.1*N(0,1) + A*sin(2*pi*f*n/16000), clamped."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = 0.1 * torch.randn(n, length, generator=g, device=device)
+    f = 100.0 + 3900.0 * torch.rand(n, 1, generator=g, device=device)
+    a = 0.05 + 0.45 * torch.rand(n, 1, generator=g, device=device)
+    t = torch.arange(length, dtype=torch.float32, device=device).unsqueeze(0)
+    x += a * torch.sin(2.0 * torch.pi * f * t / 16000.0)
+    return x.clamp_(-1.0, 1.0)
+
+
+def cpu_baseline(target_seconds=12.0):
+    """Reference CPU path restated (oracle/): features one clip at a time
+    (precompute_features.py:124-130), then batch-8 forward + argmax (evaluate.py:79-86), 32 clips."""
+    from oracle import features_ref, model_ref
+    from sir_amd import synth
+    clips = synth.synth_clips(32, CLIP_LEN, seed=1234)
+    sd = synth.synth_state_dict(NUM_CLASSES, seed=0)
+
+    def one_pass():
+        feats = [features_ref.pad_or_trim(features_ref.extract_features_f32(c)) for c in clips]
+        preds = []
+        with torch.no_grad():
+            for i in range(0, 32, 8):
+                preds.append(model_ref.forward(sd, torch.stack(feats[i:i + 8])).argmax(1))
+        return torch.cat(preds)
+
+    def timed(threads):
+        torch.set_num_threads(threads)
+        one_pass()
+        t0 = time.perf_counter()
+        one_pass()
+        dt = time.perf_counter() - t0
+        reps = max(1, min(50, int(target_seconds / 2 / max(dt, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pred = one_pass()
+        return 32 * reps / (time.perf_counter() - t0), reps, pred
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    all_rate, reps, pred = timed(cores)
+    one_rate, _, _ = timed(1)
+    torch.set_num_threads(cores)
+    return {"value": round(all_rate, 2), "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x (32 synthetic 3 s clips: torch.stft features one clip at a time + batch-8 "
+                      f"fp32 forward + argmax), oracle/ restatement of the reference CPU path",
+            "single_thread_value": round(one_rate, 2)}, pred
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from sir_amd import _native, synth
+    from sir_amd.featurizer import get_featurizer
+    from sir_amd.models.models import CNNAudioGRU
+    if not os.path.exists(_native.LIB_PATH):
+        if rank == 0:
+            _native.build()
+        if dist is not None:
+            dist.barrier()
+    lib = _native.lib()
+
+    sd = synth.synth_state_dict(NUM_CLASSES, seed=0)
+    model = CNNAudioGRU(NUM_CLASSES)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    fz = get_featurizer()
+    pool = [device_clips(BATCH, CLIP_LEN, 1234 + 1000 * rank + i, dev) for i in range(N_POOL)]
+    lengths = torch.full((BATCH,), CLIP_LEN, dtype=torch.int32, device=dev)
+    feats = torch.empty(BATCH, 64, T_PAD, device=dev)
+    preds = [None]
+
+    def step(i):
+        fz(pool[i % N_POOL], lengths, t_pad=T_PAD, out=feats)
+        _, preds[0] = model.predict(feats)
+
+    nk = lib.sir_profile_kernel_count()
+    names = [lib.sir_profile_kernel_name(i).decode() for i in range(nk)]
+
+    def collect():
+        ms = (C.c_double * nk)()
+        cnt = (C.c_int64 * nk)()
+        _native.check(lib.sir_profile_collect(fz.handle, ms, cnt, nk), "sir_profile_collect")
+        return {names[i]: (ms[i] / cnt[i] if cnt[i] else 0.0) for i in range(nk)}, {names[i]: cnt[i] for i in range(nk)}
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+
+    # untimed: per-kernel HIP-event times of a few steps -> pick the dominant kernel
+    lib.sir_profile_enable(fz.handle, 1, -1)
+    for i in range(5):
+        step(i)
+    torch.cuda.synchronize()
+    kernel_ms, _ = collect()
+    dominant = max(kernel_ms, key=kernel_ms.get)
+    lib.sir_profile_enable(fz.handle, 2, names.index(dominant))
+
+    # timed region: exactly K steps, barrier + synchronize on both sides; the dominant kernel is
+    # bracketed by a HIP event pair on its own stream (2 events per step)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    dom_ms, dom_cnt = collect()
+    lib.sir_profile_enable(fz.handle, 0, -1)
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        total_utts = BATCH * world * args.steps
+        value = total_utts / elapsed
+        d_ms = dom_ms[dominant]
+        if dominant in FLOPS_PER_UTT:
+            achieved = FLOPS_PER_UTT[dominant] * BATCH / (d_ms * 1e-3) / 1e12
+            roofline = {"kernel": dominant, "bound": "mfma", "achieved": round(achieved, 3),
+                        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                        "traffic": None, "avg_launch_ms": round(d_ms, 5), "launches": dom_cnt[dominant],
+                        "flops_per_launch": FLOPS_PER_UTT[dominant] * BATCH}
+        else:
+            achieved = FEATURE_BYTES_PER_UTT * BATCH / (d_ms * 1e-3) / 1e9
+            roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None,
+                        "avg_launch_ms": round(d_ms, 5), "launches": dom_cnt[dominant],
+                        "bytes_per_launch": FEATURE_BYTES_PER_UTT * BATCH}
+        feat_ms = kernel_ms.get("feat_frames", 0.0) + kernel_ms.get("feat_normalise", 0.0)
+        out = {
+            "metric": "utterances/sec (16 kHz, 3 s clips), inference: HIP STFT+mel+CNN/BiGRU forward + argmax",
+            "value": round(value, 1), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "1xMI355X inference (BASELINE configs[1]): batch=256 synthetic 16 kHz / 3 s clips "
+                                   "resident in HBM -> 64-mel log-mel [64,200] -> CNNAudioGRU(31) forward -> argmax",
+                       "batch_per_gpu": BATCH, "clip_samples": CLIP_LEN, "n_mels": 64, "frames": T_PAD,
+                       "num_classes": NUM_CLASSES, "parallelism": f"utterance-sharded x{world}, no data-path collective"},
+            "roofline": roofline,
+            "kernels_avg_ms": {k: round(v, 5) for k, v in kernel_ms.items()},
+            "features_stage": {"bound": "hbm", "avg_ms": round(feat_ms, 5),
+                               "achieved_GBs": round(FEATURE_BYTES_PER_UTT * BATCH / (feat_ms * 1e-3) / 1e9, 1) if feat_ms else None,
+                               "peak_GBs": PEAK_HBM_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, cpu_pred = cpu_baseline()
+            out["cpu_baseline"] = base
+            out["speedup_vs_cpu_all_cores"] = round(value / base["value"], 1)
+            # parity flag on the very sample the CPU baseline ran: predicted indices identical
+            clips = synth.synth_clips(32, CLIP_LEN, seed=1234).to(dev)
+            _, gpu_pred = model.predict(fz(clips))
+            out["parity"] = {"argmax_identical_on_cpu_sample": bool(torch.equal(gpu_pred.cpu(), cpu_pred))}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

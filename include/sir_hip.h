@@ -1,0 +1,147 @@
+/*
+ * sir_hip.h -- C ABI of the MI355X-native speech-intent hot path (libsir_hip.so).
+ *
+ * The reference (avi2924/Speech-Intent-Recognizer) is pure Python on torch/torchaudio and has
+ * no FFI of its own; its boundary for this path is the Python surface listed below.  Each entry
+ * point here names the reference call it replaces (file:line under /root/reference).  The Python
+ * host layer (speech-intent-recognizer_amd/) binds these with ctypes and keeps the reference's
+ * signatures; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions: plain C, no torch types.  Unless stated, every pointer is a DEVICE pointer owned by
+ * the caller; `stream` is a hipStream_t passed as void*.  All calls are asynchronous on `stream`,
+ * allocate nothing, and return 0 on success or a negative SIR_E* code (never throw);
+ * sir_last_error() gives the message of the last failure on the calling thread.
+ */
+#ifndef SIR_HIP_H
+#define SIR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIR_ABI_VERSION 1
+
+#define SIR_OK 0
+#define SIR_EINVAL (-1)   /* bad argument (shape, alignment, NULL) */
+#define SIR_ENOMEM (-2)   /* workspace too small / hipMalloc failed */
+#define SIR_EHIP (-3)     /* HIP runtime error */
+#define SIR_EUNSUPPORTED (-4)
+
+#define SIR_WAVE_F32 0
+#define SIR_WAVE_I16 1    /* PCM16; dequantised as s / 32768 (torchaudio.load convention) */
+
+typedef struct sir_handle sir_handle;
+
+/* Feature-extractor configuration.
+ * Replaces AudioFeatureExtractor.__init__ (scripts/precompute_features.py:21-36), i.e.
+ * torchaudio MelSpectrogram(sample_rate, n_fft, hop_length, n_mels) + AmplitudeToDB() with their
+ * defaults: win_length = n_fft, periodic Hann, power 2, center + reflect pad, HTK mel, norm None,
+ * f_min 0, f_max sample_rate/2, 10*log10(max(x,1e-10)).
+ * `window` / `mel_fb` are optional HOST arrays (n_fft floats; [n_fft/2+1][n_mels] dense, row-major)
+ * so that the host can hand over torch's own float32 tables bit for bit; NULL = computed in double
+ * here and rounded to float. */
+typedef struct sir_feature_config {
+    int sample_rate;   /* 16000 */
+    int n_fft;         /* 1024 (the only size built) */
+    int hop_length;    /* 512  (= n_fft/2, the only hop built) */
+    int n_mels;        /* 64 (<= 64) */
+    float f_min;       /* 0 */
+    float f_max;       /* sample_rate/2 */
+    const float* window;
+    const float* mel_fb;
+} sir_feature_config;
+
+/* Optional fused augmentation (scripts/augment.py:6-28 time_shift, :82-96 add_noise on the
+ * waveform; scripts/dataset.py:160-176 SpecAugment masks on the features).  Any pointer may be
+ * NULL (= that augmentation off).  All arrays are DEVICE arrays of length batch. */
+typedef struct sir_augment {
+    const int32_t* shift;        /* samples; >0 delays (zero fill on the left), <0 advances */
+    const float* noise_sigma;    /* N(0, sigma^2) added per sample, counter-based RNG */
+    uint64_t noise_seed;
+    const int32_t* time_mask;    /* [batch][2] = {start frame, width}, width 0 = none */
+    const int32_t* freq_mask;    /* [batch][2] = {start mel,   width} */
+} sir_augment;
+
+int sir_abi_version(void);
+const char* sir_last_error(void);
+
+/* Create / destroy a handle.  Uploads window, twiddles and the sparse mel filterbank to the
+ * current HIP device (the only allocating calls).  Host-synchronous. */
+int sir_create(const sir_feature_config* cfg, sir_handle** out);
+int sir_destroy(sir_handle* h);
+
+/* ---- feature path --------------------------------------------------------------------------
+ * sir_features_fwd replaces, for a whole batch in one launch pair,
+ *   AudioFeatureExtractor.extract_features  scripts/precompute_features.py:59-73
+ *     (truncate is done by the caller through `lengths`; mel power, dB, whole-utterance z-norm)
+ *   FSCIntentDataset.extract_features       scripts/dataset.py:137-152  (same arithmetic)
+ *   pad / trim to t_pad frames              scripts/dataset.py:109-113, scripts/train.py:58-62
+ * wave   : [batch][wave_stride] samples, f32 or i16 (wave_dtype), only [0, lengths[b]) is read
+ * lengths: device int32[batch]; a clip with length <= n_fft/2 yields an all-zero row (the reference
+ *          fails in torch.stft's reflect pad and substitutes zeros, dataset.py:121-123,156-158)
+ * out    : [batch][n_mels][t_pad] f32; frames >= 1 + length/hop are zero
+ * db_out : optional (NULL = off) [batch][n_mels][t_pad] f32 copy of the un-normalised dB values
+ *          (10*log10(max(mel,1e-10)), zero in the padding) -- the AmplitudeToDB output of
+ *          precompute_features.py:67, exposed so that the mel/dB stage can be checked on its own
+ * workspace: sir_features_workspace_bytes(batch, max_len) bytes, 16-byte aligned */
+size_t sir_features_workspace_bytes(const sir_handle* h, int batch, int max_len);
+int sir_features_fwd(sir_handle* h, const void* wave, int wave_dtype, int64_t wave_stride,
+                     const int32_t* lengths, int batch, int max_len, float* out, int t_pad,
+                     float* db_out, void* workspace, size_t workspace_bytes, const sir_augment* aug,
+                     void* stream);
+
+/* ---- model path ----------------------------------------------------------------------------
+ * Device pointers to the reference's parameters/buffers under their state_dict names
+ * (models/models.py:10-39): index 0..2 = conv1..3 / bn1..3; GRU index = 2*layer + reverse. */
+typedef struct sir_model_weights {
+    const float* conv_w[3];      /* [32,1,3,3] [64,32,3,3] [128,64,3,3], no bias */
+    const float* bn_w[3];
+    const float* bn_b[3];
+    const float* bn_mean[3];     /* running_mean */
+    const float* bn_var[3];      /* running_var  */
+    const float* gru_w_ih[4];    /* [768,1024] x2, [768,512] x2 ; gate order r,z,n */
+    const float* gru_w_hh[4];    /* [768,256] */
+    const float* gru_b_ih[4];    /* [768] */
+    const float* gru_b_hh[4];    /* [768] */
+    const float* attn_w;         /* [1,512] */
+    const float* attn_b;         /* [1] */
+    const float* fc_w;           /* [num_classes,512] */
+    const float* fc_b;           /* [num_classes] */
+    int num_classes;             /* <= 64 */
+} sir_model_weights;
+
+/* sir_model_infer replaces CNNAudioGRU.forward in eval() (models/models.py:41-68) followed by
+ * torch.argmax(outputs, dim=1) (scripts/evaluate.py:82-83) / torch.max (scripts/train.py:149).
+ * feats  : [batch][64][t_frames] f32 (t_frames >= 8; 200 on the training path)
+ * logits : [batch][num_classes] f32
+ * argmax : int64[batch] or NULL
+ * workspace: sir_model_workspace_bytes(batch, t_frames, 0) bytes, 256-byte aligned */
+size_t sir_model_workspace_bytes(const sir_handle* h, int batch, int t_frames, int train);
+/* Byte offsets of the intermediate buffers inside the workspace, in the order
+ *   0 conv1 out NHWC [B][32][T/2][32]   1 conv2 out NHWC [B][16][T/4][64]
+ *   2 GRU input [B][S][1024] (feature = c*8+h, models.py:55-57)   3 input projections [B*S][1536]
+ *   4 GRU layer-0 out [B][S][512]   5 GRU layer-1 out [B][S][512]   6 context [B][512]  ...
+ * so that tests can check every stage against the oracle.  Returns the number of buffers. */
+int sir_model_workspace_offsets(const sir_handle* h, int batch, int t_frames, int train,
+                                size_t* offsets, int n);
+int sir_model_infer(sir_handle* h, const sir_model_weights* w, const float* feats, int batch,
+                    int t_frames, float* logits, int64_t* argmax, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* ---- measurement -----------------------------------------------------------------------------
+ * HIP-event timing of the kernels of the path, recorded on the stream they are launched on
+ * (bench.py's roofline figures come from here).  mode 0 = off, 1 = every kernel, 2 = only
+ * `kernel_id`.  sir_profile_collect waits for the recorded events, returns per-kernel total
+ * milliseconds and launch counts since the last collect (arrays of length n), and resets. */
+int sir_profile_kernel_count(void);
+const char* sir_profile_kernel_name(int kernel_id);
+int sir_profile_enable(sir_handle* h, int mode, int kernel_id);
+int sir_profile_collect(sir_handle* h, double* total_ms, int64_t* launches, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIR_HIP_H */

@@ -48,12 +48,14 @@ def _bn(x, sd, i, train, new_stats=None):
     return (x - mean[None, :, None, None]) * (inv * g)[None, :, None, None] + b[None, :, None, None]
 
 
-def cnn_stack(x, sd, train=False, new_stats=None):
+def cnn_stack(x, sd, train=False, new_stats=None, stages=None):
     """x [B,1,H,W] -> [B,128,H/8,W/8]  (models.py:50-52)."""
     for i in (1, 2, 3):
         x = F.conv2d(x, sd[f"conv{i}.weight"], bias=None, stride=1, padding=1)
         x = _bn(x, sd, i, train, new_stats)
         x = F.max_pool2d(torch.relu(x), 2)
+        if stages is not None:
+            stages[f"conv{i}"] = x
     return x
 
 
@@ -76,7 +78,7 @@ def gru_direction(x, w_ih, w_hh, b_ih, b_hh, reverse):
     return torch.stack(outs, dim=1)
 
 
-def bigru(x, sd, dropout_mask=None):
+def bigru(x, sd, dropout_mask=None, stages=None):
     """2-layer bidirectional GRU, batch_first.  ``dropout_mask`` ([B,T,512], already scaled
     by 1/(1-p)) stands for the inter-layer dropout of models.py:32; None = no dropout."""
     for layer in (0, 1):
@@ -85,6 +87,8 @@ def bigru(x, sd, dropout_mask=None):
         rev = gru_direction(x, sd[f"gru.weight_ih_l{layer}_reverse"], sd[f"gru.weight_hh_l{layer}_reverse"],
                             sd[f"gru.bias_ih_l{layer}_reverse"], sd[f"gru.bias_hh_l{layer}_reverse"], True)
         x = torch.cat([fwd, rev], dim=2)
+        if stages is not None:
+            stages[f"gru_l{layer}"] = x
         if layer == 0 and dropout_mask is not None:
             x = x * dropout_mask
     return x
@@ -94,12 +98,12 @@ def forward(sd, x, train=False, new_stats=None, dropout_mask=None, stages=None):
     """x [B,64,T] or [B,1,64,T] -> logits [B,C]  (models.py:41-68)."""
     if x.dim() == 3:
         x = x.unsqueeze(1)
-    x = cnn_stack(x, sd, train, new_stats)
+    x = cnn_stack(x, sd, train, new_stats, stages)
     b, c, h, w = x.shape
     seq = x.permute(0, 3, 1, 2).contiguous().view(b, w, c * h)     # feature = c*h_dim + h
     if stages is not None:
         stages["gru_in"] = seq
-    y = bigru(seq, sd, dropout_mask)
+    y = bigru(seq, sd, dropout_mask, stages)
     if stages is not None:
         stages["gru_out"] = y
     scores = y @ sd["attention.weight"].t() + sd["attention.bias"]  # [B,T,1]

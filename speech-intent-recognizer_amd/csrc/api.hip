@@ -1,0 +1,152 @@
+// C ABI entry points of libsir_hip.so (see include/sir_hip.h): handle management, error state,
+// argument validation.  Kernels live in features.hip / model_*.hip.
+#include "sir_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void sir_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int sir_check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return SIR_OK;
+    sir_set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
+    return SIR_EHIP;
+}
+
+extern "C" int sir_abi_version(void) { return SIR_ABI_VERSION; }
+extern "C" const char* sir_last_error(void) { return g_err; }
+
+template <typename T>
+static int upload(T** dst, const std::vector<T>& src) {
+    SIR_HIP_TRY(hipMalloc((void**)dst, src.size() * sizeof(T)));
+    SIR_HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SIR_OK;
+}
+
+extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
+    if (!cfg || !out) { sir_set_error("sir_create: NULL argument"); return SIR_EINVAL; }
+    if (cfg->n_fft != SIR_NFFT || cfg->hop_length != SIR_HOP) {
+        sir_set_error("sir_create: only n_fft=1024 / hop=512 are built (got %d / %d)", cfg->n_fft, cfg->hop_length);
+        return SIR_EUNSUPPORTED;
+    }
+    if (cfg->n_mels < 1 || cfg->n_mels > SIR_MAX_MELS || cfg->sample_rate <= 0) {
+        sir_set_error("sir_create: n_mels=%d sample_rate=%d out of range", cfg->n_mels, cfg->sample_rate);
+        return SIR_EINVAL;
+    }
+    sir_handle* h = new sir_handle();
+    h->prof_mode = 0; h->prof_only = -1;
+    h->tw512 = nullptr; h->tw1024 = nullptr; h->window = nullptr; h->melw = nullptr; h->mel_start = nullptr;
+    h->cfg = *cfg;
+    h->cfg.window = nullptr;
+    h->cfg.mel_fb = nullptr;
+    if (sir_check_hip(hipGetDevice(&h->device), "hipGetDevice") != SIR_OK) { delete h; return SIR_EHIP; }
+
+    const double PI = 3.14159265358979323846;
+    std::vector<float2> tw512(512), tw1024(SIR_NFREQ);
+    for (int j = 0; j < 512; ++j) tw512[j] = make_float2((float)cos(-2.0 * PI * j / 512.0), (float)sin(-2.0 * PI * j / 512.0));
+    for (int k = 0; k < SIR_NFREQ; ++k) tw1024[k] = make_float2((float)cos(-2.0 * PI * k / 1024.0), (float)sin(-2.0 * PI * k / 1024.0));
+    std::vector<float> window(SIR_NFFT);
+    for (int n = 0; n < SIR_NFFT; ++n)
+        window[n] = cfg->window ? cfg->window[n] : (float)(0.5 - 0.5 * cos(2.0 * PI * n / SIR_NFFT));
+
+    // dense HTK filterbank (torchaudio melscale_fbanks, norm=None), then compacted per filter
+    const int nm = cfg->n_mels;
+    std::vector<float> fb((size_t)SIR_NFREQ * nm);
+    if (cfg->mel_fb) {
+        memcpy(fb.data(), cfg->mel_fb, fb.size() * sizeof(float));
+    } else {
+        const double f_lo = cfg->f_min, f_hi = cfg->f_max > 0 ? cfg->f_max : cfg->sample_rate / 2;
+        const double mmin = 2595.0 * log10(1.0 + f_lo / 700.0), mmax = 2595.0 * log10(1.0 + f_hi / 700.0);
+        std::vector<double> fpts(nm + 2);
+        for (int i = 0; i < nm + 2; ++i) fpts[i] = 700.0 * (pow(10.0, (mmin + (mmax - mmin) * i / (nm + 1)) / 2595.0) - 1.0);
+        for (int k = 0; k < SIR_NFREQ; ++k) {
+            const double f = (double)(cfg->sample_rate / 2) * k / (SIR_NFREQ - 1);
+            for (int j = 0; j < nm; ++j) {
+                const double up = (f - fpts[j]) / (fpts[j + 1] - fpts[j]), down = (fpts[j + 2] - f) / (fpts[j + 2] - fpts[j + 1]);
+                const double v = up < down ? up : down;
+                fb[(size_t)k * nm + j] = (float)(v > 0.0 ? v : 0.0);
+            }
+        }
+    }
+    std::vector<int> start(SIR_MAX_MELS, 0), count(SIR_MAX_MELS, 0);
+    int max_taps = 1;
+    for (int j = 0; j < nm; ++j) {
+        int lo = -1, hi = -1;
+        for (int k = 0; k < SIR_NFREQ; ++k)
+            if (fb[(size_t)k * nm + j] != 0.0f) { if (lo < 0) lo = k; hi = k; }
+        if (lo >= 0) { start[j] = lo; count[j] = hi - lo + 1; }
+        if (count[j] > max_taps) max_taps = count[j];
+    }
+    std::vector<float> melw((size_t)max_taps * SIR_MAX_MELS, 0.0f);
+    for (int j = 0; j < nm; ++j)
+        for (int i = 0; i < count[j]; ++i) melw[(size_t)i * SIR_MAX_MELS + j] = fb[(size_t)(start[j] + i) * nm + j];
+    h->max_taps = max_taps;
+
+    int rc = upload(&h->tw512, tw512);
+    if (rc == SIR_OK) rc = upload(&h->tw1024, tw1024);
+    if (rc == SIR_OK) rc = upload(&h->window, window);
+    if (rc == SIR_OK) rc = upload(&h->melw, melw);
+    if (rc == SIR_OK) rc = upload(&h->mel_start, start);
+    if (rc != SIR_OK) { sir_destroy(h); return rc; }
+    *out = h;
+    return SIR_OK;
+}
+
+extern "C" int sir_destroy(sir_handle* h) {
+    if (!h) return SIR_OK;
+    (void)hipFree(h->tw512); (void)hipFree(h->tw1024); (void)hipFree(h->window);
+    (void)hipFree(h->melw); (void)hipFree(h->mel_start);
+    for (auto& r : h->prof_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto e : h->prof_free) (void)hipEventDestroy(e);
+    delete h;
+    return SIR_OK;
+}
+
+extern "C" int sir_features_fwd(sir_handle* h, const void* wave, int wave_dtype, int64_t wave_stride,
+                                const int32_t* lengths, int batch, int max_len, float* out, int t_pad,
+                                float* db_out, void* workspace, size_t workspace_bytes, const sir_augment* aug,
+                                void* stream) {
+    return sir_features_launch(h, wave, wave_dtype, wave_stride, lengths, batch, max_len, out, t_pad, db_out,
+                               workspace, workspace_bytes, aug, (hipStream_t)stream);
+}
+
+// ---- event profiling ------------------------------------------------------------------------
+static const char* const kKernelNames[SIR_K_COUNT] = {
+    "feat_frames", "feat_normalise", "weight_prep", "conv1_bn_relu_pool", "conv2_mfma_bn_relu_pool",
+    "conv3_mfma_bn_relu_pool", "gemm_ih_l0", "gru_recurrence_l0", "gemm_ih_l1", "gru_recurrence_l1",
+    "attention_pool", "fc_head"};
+
+extern "C" int sir_profile_kernel_count(void) { return SIR_K_COUNT; }
+extern "C" const char* sir_profile_kernel_name(int id) { return (id >= 0 && id < SIR_K_COUNT) ? kKernelNames[id] : ""; }
+
+extern "C" int sir_profile_enable(sir_handle* h, int mode, int kernel_id) {
+    if (!h || mode < 0 || mode > 2) { sir_set_error("sir_profile_enable: bad argument"); return SIR_EINVAL; }
+    h->prof_mode = mode;
+    h->prof_only = kernel_id;
+    return SIR_OK;
+}
+
+extern "C" int sir_profile_collect(sir_handle* h, double* total_ms, int64_t* launches, int n) {
+    if (!h || !total_ms || !launches) { sir_set_error("sir_profile_collect: NULL argument"); return SIR_EINVAL; }
+    for (int i = 0; i < n; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
+    for (auto& r : h->prof_pending) {
+        SIR_HIP_TRY(hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        SIR_HIP_TRY(hipEventElapsedTime(&ms, r.e0, r.e1));
+        if (r.id < n) { total_ms[r.id] += ms; launches[r.id] += 1; }
+        h->prof_free.push_back(r.e0);
+        h->prof_free.push_back(r.e1);
+    }
+    h->prof_pending.clear();
+    return SIR_OK;
+}

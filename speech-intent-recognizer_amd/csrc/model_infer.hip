@@ -1,0 +1,170 @@
+// sir_model_infer: eval-mode CNNAudioGRU.forward + argmax (models/models.py:41-68, scripts/evaluate.py:82-83)
+// as a fixed sequence of hand-written kernels on one stream.  See model_kernels.h for the kernels.
+#include "model_kernels.h"
+
+namespace {
+
+enum WsBuf {
+    WS_A1 = 0,   // conv1 out  NHWC [B][32][T/2][32]
+    WS_A2,       // conv2 out  NHWC [B][16][T/4][64]
+    WS_X0,       // conv3 out = GRU input [B][S][1024], feature = c*8 + h
+    WS_GI,       // input projections of the current GRU layer [B*S][1536]
+    WS_Y0,       // GRU layer 0 output [B][S][512]
+    WS_Y1,       // GRU layer 1 output [B][S][512]
+    WS_CTX,      // attention-pooled context [B][512]
+    WS_WP2,      // prepared conv2 weights [36][64][8]
+    WS_WP3,      // prepared conv3 weights [72][128][8]
+    WS_BN,       // folded BN: scale[224] then shift[224] (channels of bn1|bn2|bn3)
+    WS_WHT,      // transposed W_hh, [4][64][768][4]
+    WS_COUNT
+};
+
+struct Dims {
+    int B, T, wp1, wp2, wp3, S;
+};
+
+bool make_dims(int batch, int t_frames, Dims* d) {
+    d->B = batch; d->T = t_frames;
+    d->wp1 = t_frames / 2; d->wp2 = d->wp1 / 2; d->wp3 = d->wp2 / 2; d->S = d->wp3;
+    return batch > 0 && d->S >= 1 && d->S <= ATT_MAX_S && batch <= 65535;
+}
+
+void ws_sizes(const Dims& d, size_t* bytes) {
+    const size_t B = d.B;
+    bytes[WS_A1] = B * 32 * d.wp1 * 32 * 4;
+    bytes[WS_A2] = B * 16 * d.wp2 * 64 * 4;
+    bytes[WS_X0] = B * d.S * 1024 * 4;
+    bytes[WS_GI] = B * d.S * 1536 * 4;
+    bytes[WS_Y0] = B * d.S * 512 * 4;
+    bytes[WS_Y1] = B * d.S * 512 * 4;
+    bytes[WS_CTX] = B * 512 * 4;
+    bytes[WS_WP2] = (size_t)36 * 64 * 8 * 4;
+    bytes[WS_WP3] = (size_t)72 * 128 * 8 * 4;
+    bytes[WS_BN] = (size_t)2 * 224 * 4;
+    bytes[WS_WHT] = (size_t)4 * 768 * 256 * 4;
+}
+
+size_t ws_layout(const Dims& d, size_t* off) {
+    size_t bytes[WS_COUNT], pos = 0;
+    ws_sizes(d, bytes);
+    for (int i = 0; i < WS_COUNT; ++i) {
+        off[i] = pos;
+        pos += sir_align_up(bytes[i], 256);
+    }
+    return pos;
+}
+
+}  // namespace
+
+extern "C" size_t sir_model_workspace_bytes(const sir_handle* h, int batch, int t_frames, int train) {
+    (void)h; (void)train;
+    Dims d;
+    if (!make_dims(batch, t_frames, &d)) return 0;
+    size_t off[WS_COUNT];
+    return ws_layout(d, off);
+}
+
+extern "C" int sir_model_workspace_offsets(const sir_handle* h, int batch, int t_frames, int train, size_t* offsets,
+                                           int n) {
+    (void)h; (void)train;
+    Dims d;
+    if (!make_dims(batch, t_frames, &d) || !offsets) { sir_set_error("sir_model_workspace_offsets: bad shape"); return SIR_EINVAL; }
+    size_t off[WS_COUNT];
+    ws_layout(d, off);
+    for (int i = 0; i < n && i < WS_COUNT; ++i) offsets[i] = off[i];
+    return WS_COUNT;
+}
+
+#define SIR_KCHECK() SIR_HIP_TRY(hipGetLastError())
+
+extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const float* feats, int batch, int t_frames,
+                               float* logits, int64_t* argmax, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!h || !w || !feats || !logits || !workspace) { sir_set_error("sir_model_infer: NULL argument"); return SIR_EINVAL; }
+    Dims d;
+    if (!make_dims(batch, t_frames, &d)) {
+        sir_set_error("sir_model_infer: unsupported shape batch=%d t_frames=%d (need t_frames >= 8)", batch, t_frames);
+        return SIR_EINVAL;
+    }
+    if (h->cfg.n_mels != 64) { sir_set_error("sir_model_infer: the model is wired for 64 mels (models.py:23)"); return SIR_EUNSUPPORTED; }
+    if (w->num_classes < 1 || w->num_classes > 64) { sir_set_error("sir_model_infer: num_classes=%d", w->num_classes); return SIR_EINVAL; }
+    size_t off[WS_COUNT];
+    const size_t need = ws_layout(d, off);
+    if (workspace_bytes < need) { sir_set_error("sir_model_infer: workspace %zu < %zu", workspace_bytes, need); return SIR_ENOMEM; }
+    if (((uintptr_t)workspace & 255) != 0) { sir_set_error("sir_model_infer: workspace must be 256-byte aligned"); return SIR_EINVAL; }
+    hipStream_t st = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    float* a1 = (float*)(ws + off[WS_A1]);
+    float* a2 = (float*)(ws + off[WS_A2]);
+    float* x0 = (float*)(ws + off[WS_X0]);
+    float* gi = (float*)(ws + off[WS_GI]);
+    float* y0 = (float*)(ws + off[WS_Y0]);
+    float* y1 = (float*)(ws + off[WS_Y1]);
+    float* ctx = (float*)(ws + off[WS_CTX]);
+    float* wp2 = (float*)(ws + off[WS_WP2]);
+    float* wp3 = (float*)(ws + off[WS_WP3]);
+    float* bns = (float*)(ws + off[WS_BN]);
+    float* bnt = bns + 224;
+    float* wht = (float*)(ws + off[WS_WHT]);
+    const int B = d.B, S = d.S;
+
+    // ---- weight preparation -------------------------------------------------------------
+    {
+    SirProfScope prof(h, SIR_K_PREP, st);
+    hipLaunchKernelGGL(prep_conv_w_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], wp2, 32, 64);
+    hipLaunchKernelGGL(prep_conv_w_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], wp3, 64, 128);
+    const int bn_c[3] = {32, 64, 128}, bn_o[3] = {0, 32, 96};
+    for (int i = 0; i < 3; ++i)
+        hipLaunchKernelGGL(prep_bn_kernel, dim3(1), dim3(128), 0, st, w->bn_w[i], w->bn_b[i], w->bn_mean[i], w->bn_var[i],
+                           bns + bn_o[i], bnt + bn_o[i], bn_c[i]);
+    for (int i = 0; i < 4; ++i)
+        hipLaunchKernelGGL(prep_whh_kernel, dim3(768), dim3(256), 0, st, w->gru_w_hh[i], wht + (size_t)i * 768 * 256);
+    }
+    SIR_KCHECK();
+
+    // ---- CNN stack ------------------------------------------------------------------------
+    { SirProfScope prof(h, SIR_K_CONV1, st);
+    hipLaunchKernelGGL(conv1_bn_relu_pool_kernel, dim3((d.wp1 + C1_PCOLS - 1) / C1_PCOLS, (32 + C1_PROWS - 1) / C1_PROWS, B),
+                       dim3(256), 0, st, feats, w->conv_w[0], bns, bnt, a1, 64, d.T, 32, d.wp1); }
+    {
+        SirProfScope prof(h, SIR_K_CONV2, st);
+        constexpr size_t lds = (size_t)(8 * 4 + 2) * (4 * 2 + 2) * 36 * 4;
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<32, 64, 4, 2, 0>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), lds, st, a1, wp2,
+                           bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2);
+    }
+    {
+        SirProfScope prof(h, SIR_K_CONV3, st);
+        constexpr size_t lds = (size_t)(8 * 2 + 2) * (4 * 4 + 2) * 36 * 4;
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<64, 128, 2, 4, 1>), dim3((d.wp2 + 15) / 16, 1, B), dim3(256), lds, st, a2, wp3,
+                           bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3);
+    }
+    SIR_KCHECK();
+
+    // ---- 2-layer bidirectional GRU ----------------------------------------------------------
+    const int M = B * S;
+    const dim3 ggrid(768 / GB_N, (M + GB_M - 1) / GB_M, 2);
+    const dim3 rgrid((B + GRU_BW - 1) / GRU_BW, 2);
+    { SirProfScope prof(h, SIR_K_GEMM_IH0, st);
+    hipLaunchKernelGGL(gemm_nt_bias_kernel, ggrid, dim3(256), 0, st, x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
+                       w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024); }
+    { SirProfScope prof(h, SIR_K_GRU0, st);
+    hipLaunchKernelGGL(gru_recurrence_kernel, rgrid, dim3(1024), 0, st, gi, wht, w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S); }
+    { SirProfScope prof(h, SIR_K_GEMM_IH1, st);
+    hipLaunchKernelGGL(gemm_nt_bias_kernel, ggrid, dim3(256), 0, st, y0, 512, w->gru_w_ih[2], w->gru_w_ih[3], 512,
+                       w->gru_b_ih[2], w->gru_b_ih[3], gi, 1536, M, 768, 512); }
+    { SirProfScope prof(h, SIR_K_GRU1, st);
+    hipLaunchKernelGGL(gru_recurrence_kernel, rgrid, dim3(1024), 0, st, gi, wht + (size_t)2 * 768 * 256, w->gru_b_hh[2],
+                       w->gru_b_hh[3], y1, B, S); }
+    SIR_KCHECK();
+
+    // ---- attention pooling + classifier head ------------------------------------------------
+    { SirProfScope prof(h, SIR_K_ATTN, st);
+    hipLaunchKernelGGL(attention_pool_kernel, dim3(B), dim3(256), 0, st, y1, w->attn_w, w->attn_b, ctx, S); }
+    SirProfScope prof_fc(h, SIR_K_FC, st);
+    hipLaunchKernelGGL(gemm_nt_bias_kernel, dim3((w->num_classes + GB_N - 1) / GB_N, (B + GB_M - 1) / GB_M, 1), dim3(256), 0, st,
+                       ctx, 512, w->fc_w, w->fc_w, 512, w->fc_b, w->fc_b, logits, w->num_classes, B, w->num_classes, 512);
+    if (argmax)
+        hipLaunchKernelGGL(argmax_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, st, logits, (long long*)argmax, B,
+                           w->num_classes);
+    SIR_KCHECK();
+    return SIR_OK;
+}

@@ -1,0 +1,443 @@
+// Device kernels of the CNN + BiGRU + attention model (inference forms), gfx950.
+// Included by model_infer.hip (and later by the training translation unit).
+//
+// Activation layout is channels-last ("NHWC") so that (a) conv outputs are stored as 128-byte
+// runs of 32 consecutive channels per pixel and (b) the implicit-GEMM convolutions read their
+// pixel-major A operand from LDS with one ds_read_b128 per four MFMA steps.
+// All contractions use v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate, an exact fmaf chain:
+// cdna guide section 3 "FP32-input MFMA") because the parity bar is identical argmax vs the fp32
+// CPU path; lane maps: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D col=l&31,
+// row=(r&3)+8*(r>>2)+4*(l>>5).
+#pragma once
+#include "sir_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define SIR_BN_EPS 1e-5f
+
+// ------------------------------------------------------------------------------------------
+// weight preparation (tiny, runs at the head of every forward so it always sees current weights)
+// ------------------------------------------------------------------------------------------
+
+// conv weight [COUT][CIN][3][3] -> wp[g][co][8], g = (ci/8)*9 + tap, e = ci%8: one wave-load of
+// the B operand (32 output channels x 8 input channels of one tap) is 1 KiB contiguous.
+__global__ void prep_conv_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int cin, int cout) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = cin * 9 * cout;
+    if (idx >= total) return;
+    const int e = idx & 7, co = (idx >> 3) % cout, g = (idx >> 3) / cout;
+    const int ci = (g / 9) * 8 + e, tap = g % 9;
+    wp[idx] = w[((size_t)co * cin + ci) * 9 + tap];
+}
+
+// eval-mode BatchNorm folded to y = x*scale + shift (models/models.py:50-52, running stats)
+__global__ void prep_bn_kernel(const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ mean,
+                               const float* __restrict__ var, float* __restrict__ scale, float* __restrict__ shift, int c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const float s = g[i] / sqrtf(var[i] + SIR_BN_EPS);
+    scale[i] = s;
+    shift[i] = b[i] - mean[i] * s;
+}
+
+// W_hh [768][256] (k contiguous) -> wt[k/4][768][4]: lane = gate row, one 16-byte load carries 4 k
+__global__ void prep_whh_kernel(const float* __restrict__ w, float* __restrict__ wt) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // over 768*256
+    if (idx >= 768 * 256) return;
+    const int e = idx & 3, row = (idx >> 2) % 768, k4 = (idx >> 2) / 768;
+    wt[idx] = w[(size_t)row * 256 + k4 * 4 + e];
+}
+
+// ------------------------------------------------------------------------------------------
+// conv1 (1 -> 32 channels) + BN + ReLU + 2x2 max-pool, direct form (K = 9: memory-bound)
+//   x [B][H=64][W] -> out NHWC [B][H/2][W/2][32];  lane&31 = channel, half-waves walk pixels
+// ------------------------------------------------------------------------------------------
+constexpr int C1_PROWS = 4, C1_PCOLS = 32;          // pooled pixels per block: 4 x 32
+constexpr int C1_TR = 2 * C1_PROWS + 2, C1_TC = 2 * C1_PCOLS + 2;
+
+__global__ __launch_bounds__(256) void conv1_bn_relu_pool_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp) {
+    __shared__ float tile[C1_TR * C1_TC];
+    const int b = blockIdx.z, py0 = blockIdx.y * C1_PROWS, px0 = blockIdx.x * C1_PCOLS;
+    const int tid = threadIdx.x, c = tid & 31, slot = tid >> 5;
+    const float* xb = x + (size_t)b * H * W;
+    for (int i = tid; i < C1_TR * C1_TC; i += 256) {
+        const int ty = i / C1_TC, tx = i - ty * C1_TC;
+        const int gy = 2 * py0 - 1 + ty, gx = 2 * px0 - 1 + tx;
+        tile[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xb[(size_t)gy * W + gx] : 0.0f;
+    }
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
+    const float s = scale[c], t = shift[c];
+    __syncthreads();
+    for (int i = 0; i < (C1_PROWS * C1_PCOLS) / 8; ++i) {
+        const int pp = slot + 8 * i, pyl = pp / C1_PCOLS, pxl = pp % C1_PCOLS;
+        const int py = py0 + pyl, px = px0 + pxl;
+        if (py >= Hp || px >= Wp) continue;
+        float in[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) in[r][q] = tile[(2 * pyl + r) * C1_TC + 2 * pxl + q];
+        float best = 0.0f;                               // ReLU floor
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float a = 0.0f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) a = fmaf(in[dy + ky][dx + kx], wk[ky * 3 + kx], a);
+                best = fmaxf(best, fmaf(a, s, t));
+            }
+        out[(((size_t)b * Hp + py) * Wp + px) * 32 + c] = best;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv 3x3 (CIN -> COUT) + BN + ReLU + 2x2 max-pool as an implicit GEMM on fp32 MFMA.
+//   M = pixels (A operand, from an NHWC input tile with halo staged in LDS),
+//   N = output channels (B operand, streamed per wave from the prepared weights in L2),
+//   K = (tap, ci).  One MFMA row tile = an 8-row x 4-col pixel patch whose bit layout
+//   m = x0 | y0<<1 | x1<<2 | y1<<3 | y2<<4 puts every 2x2 pool window in registers 4q..4q+3 of
+//   one lane, so pooling is four v_max per pooled pixel with no cross-lane traffic, and the
+//   pooled store is 32 consecutive channels (128 B) per half-wave.
+//   Workgroup = 4 waves x 2 patches = PR x PC patches; all COUT channels per wave (NT tiles).
+// OUT_MODE 0: NHWC [B][Hp][Wp][COUT];  1: GRU input [B][Wp][COUT*Hp] with feature = co*Hp + py
+//   (the permute(0,3,1,2).view of models/models.py:55-57, folded into the store).
+// ------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int PR, int PC, int OUT_MODE>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp) {
+    constexpr int NT = COUT / 32, MT = 2, CK = 32, PS = CK + 4;
+    constexpr int TR = 8 * PR, TC = 4 * PC, TROWS = TR + 2, TCOLS = TC + 2;
+    static_assert(PR * PC == 8 && CIN % CK == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.z, ty0 = blockIdx.y * TR, tx0 = blockIdx.x * TC;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m = lane & 31, kh = lane >> 5;
+    const int pxl = (m & 1) + 2 * ((m >> 2) & 1);
+    const int pyl = ((m >> 1) & 1) + 2 * ((m >> 3) & 1) + 4 * ((m >> 4) & 1);
+    int aoff[MT], pr_[MT], pc_[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int pi = 2 * wv + mt;
+        pr_[mt] = pi / PC;
+        pc_[mt] = pi % PC;
+        aoff[mt] = ((8 * pr_[mt] + pyl) * TCOLS + 4 * pc_[mt] + pxl) * PS + kh * 4;
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    const float4* wp4 = reinterpret_cast<const float4*>(wp);     // float4 index = (g*COUT + co)*2 + kh
+    const float* xb = x + (size_t)b * H * W * CIN;
+
+    for (int cc = 0; cc < CIN / CK; ++cc) {
+        if (cc) __syncthreads();
+        for (int idx = tid; idx < TROWS * TCOLS * 8; idx += 256) {
+            const int pix = idx >> 3, part = idx & 7;
+            const int tyy = pix / TCOLS, txx = pix - tyy * TCOLS;
+            const int gy = ty0 - 1 + tyy, gx = tx0 - 1 + txx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4*>(xb + ((size_t)gy * W + gx) * CIN + cc * CK + part * 4);
+            *reinterpret_cast<float4*>(lds + pix * PS + part * 4) = v;
+        }
+        __syncthreads();
+        float4 bcur[NT], bnxt[NT];
+        const int g0 = cc * 36;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bcur[nt] = wp4[((size_t)g0 * COUT + nt * 32 + m) * 2 + kh];
+#pragma unroll
+        for (int it = 0; it < 36; ++it) {
+            const int cgl = it / 9, tap = it % 9, ky = tap / 3, kx = tap % 3;
+            if (it + 1 < 36) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bnxt[nt] = wp4[((size_t)(g0 + it + 1) * COUT + nt * 32 + m) * 2 + kh];
+            }
+            float4 a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                a[mt] = *reinterpret_cast<const float4*>(lds + aoff[mt] + (ky * TCOLS + kx) * PS + cgl * 8);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bcur[nt].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bcur[nt].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bcur[nt].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bcur[nt].w, acc[mt][nt], 0, 0, 0);
+                }
+            if (it + 1 < 36) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bcur[nt] = bnxt[nt];
+            }
+        }
+    }
+
+    // epilogue: BN (folded) -> ReLU -> 2x2 max over registers 4q..4q+3 -> store
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int PX = (tx0 + 4 * pc_[mt]) / 2 + kh;
+        const int PYb = (ty0 + 8 * pr_[mt]) / 2;
+        if (PX >= Wp) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = nt * 32 + m;
+            const float s = scale[co], t = shift[co];
+            float pooled[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v = fmaxf(v, fmaf(acc[mt][nt][4 * q + r], s, t));
+                pooled[q] = v;
+            }
+            if (OUT_MODE == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (PYb + q < Hp) out[(((size_t)b * Hp + PYb + q) * Wp + PX) * COUT + co] = pooled[q];
+            } else {
+                float* o = out + ((size_t)b * Wp + PX) * (COUT * Hp) + (size_t)co * Hp + PYb;
+                if ((Hp & 3) == 0) {
+                    *reinterpret_cast<float4*>(o) = make_float4(pooled[0], pooled[1], pooled[2], pooled[3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (PYb + q < Hp) o[q] = pooled[q];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// C[m][z*N + n] = sum_k A[m][k] * Bz[n][k] + biasz[n]    (fp32 MFMA, "NT": both operands k-contiguous)
+//   used for the GRU input projections (z = direction) and the classifier head.
+//   128 x 64 block tile, BK = 32, 4 waves as 2(M) x 2(N), wave tile 64 x 32; LDS rows padded to 36
+//   floats so the ds_read_b128 operand reads are bank-conflict-free; global->register prefetch of
+//   the next k-tile overlaps the MFMAs of the current one.
+// ------------------------------------------------------------------------------------------
+constexpr int GB_M = 128, GB_N = 64, GB_K = 32, GB_S = GB_K + 4;
+
+__global__ __launch_bounds__(256) void gemm_nt_bias_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ B0, const float* __restrict__ B1, int ldb,
+    const float* __restrict__ bias0, const float* __restrict__ bias1, float* __restrict__ C, int ldc,
+    int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) float As[GB_M * GB_S];
+    __shared__ __attribute__((aligned(16))) float Bs[GB_N * GB_S];
+    const int z = blockIdx.z;
+    const float* __restrict__ B = z ? B1 : B0;
+    const float* __restrict__ bias = z ? bias1 : bias0;
+    const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1, m = lane & 31, kh = lane >> 5;
+
+    float4 ra[4], rb[2];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 3, c4 = idx & 7;
+            ra[i] = (m0 + row < M) ? *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * lda + kt * GB_K + c4 * 4)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 3, c4 = idx & 7;
+            rb[i] = (n0 + row < N) ? *reinterpret_cast<const float4*>(B + (size_t)(n0 + row) * ldb + kt * GB_K + c4 * 4)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 3, c4 = idx & 7;
+            *reinterpret_cast<float4*>(As + row * GB_S + c4 * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 3, c4 = idx & 7;
+            *reinterpret_cast<float4*>(Bs + row * GB_S + c4 * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+
+    const int nk = K / GB_K;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float4 a0 = *reinterpret_cast<const float4*>(As + (wm * 64 + m) * GB_S + kk * 8 + kh * 4);
+            const float4 a1 = *reinterpret_cast<const float4*>(As + (wm * 64 + 32 + m) * GB_S + kk * 8 + kh * 4);
+            const float4 bq = *reinterpret_cast<const float4*>(Bs + (wn * 32 + m) * GB_S + kk * 8 + kh * 4);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bq.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bq.x, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bq.y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bq.y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bq.z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bq.z, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bq.w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bq.w, acc[1], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+    const int n = n0 + wn * 32 + m;
+    if (n < N) {
+        const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < M) C[(size_t)row * ldc + (size_t)z * N + n] = acc[mt][r] + bv;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// GRU recurrence of one layer, both directions (torch.nn.GRU cell, gate order r,z,n, h0 = 0):
+//   gi  [B*S][1536]   = x W_ih^T + b_ih for both directions (from the GEMM above)
+//   wt  [2][64][768][4] transposed W_hh (prep_whh_kernel), bhh [2][768]
+//   y   [B][S][512]   direction d writes columns d*256 .. d*256+255
+// One workgroup = 4 utterances of one direction for all S steps: no inter-workgroup traffic.
+// 1024 threads = 256 hidden units x 4 K-slices; each thread accumulates 3 gates x 4 utterances
+// over its 64-wide K slice (W_hh streamed from L2 as 16-byte coalesced loads, h broadcast from
+// LDS), slices are summed through LDS, then thread (u, b) applies the gate math.
+// ------------------------------------------------------------------------------------------
+constexpr int GRU_H = 256, GRU_BW = 4;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(1024) void gru_recurrence_kernel(
+    const float* __restrict__ gi, const float* __restrict__ wt, const float* __restrict__ bhh0,
+    const float* __restrict__ bhh1, float* __restrict__ y, int B, int S) {
+    __shared__ __attribute__((aligned(16))) float hs[GRU_BW * GRU_H];            // h[b][k]
+    __shared__ float ps[4 * GRU_BW * 3 * GRU_H];                                  // partial[ks][b][gate*256+u]
+    const int dir = blockIdx.y, b0 = blockIdx.x * GRU_BW;
+    const int tid = threadIdx.x, u = tid & 255, ks = tid >> 8;
+    const float4* w4 = reinterpret_cast<const float4*>(wt) + (size_t)dir * 64 * 768;
+    const float* bhh = dir ? bhh1 : bhh0;
+    const int bme = ks;                                   // utterance this thread finishes
+    const bool bvalid = (b0 + bme) < B;
+    const float bh_r = bhh[u], bh_z = bhh[256 + u], bh_n = bhh[512 + u];
+    hs[tid] = 0.0f;
+    float hprev = 0.0f;
+    __syncthreads();
+    for (int step = 0; step < S; ++step) {
+        const int t = dir ? (S - 1 - step) : step;
+        float gr = 0.f, gz = 0.f, gn = 0.f;
+        if (bvalid) {
+            const float* g = gi + ((size_t)(b0 + bme) * S + t) * 1536 + dir * 768;
+            gr = g[u]; gz = g[256 + u]; gn = g[512 + u];
+        }
+        float acc[3][GRU_BW];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int bb = 0; bb < GRU_BW; ++bb) acc[g][bb] = 0.0f;
+#pragma unroll 4
+        for (int k4 = ks * 16; k4 < ks * 16 + 16; ++k4) {
+            const float4 wr = w4[(size_t)k4 * 768 + u];
+            const float4 wz = w4[(size_t)k4 * 768 + 256 + u];
+            const float4 wn = w4[(size_t)k4 * 768 + 512 + u];
+#pragma unroll
+            for (int bb = 0; bb < GRU_BW; ++bb) {
+                const float4 h4 = *reinterpret_cast<const float4*>(hs + bb * GRU_H + k4 * 4);
+                acc[0][bb] = fmaf(wr.x, h4.x, acc[0][bb]); acc[0][bb] = fmaf(wr.y, h4.y, acc[0][bb]);
+                acc[0][bb] = fmaf(wr.z, h4.z, acc[0][bb]); acc[0][bb] = fmaf(wr.w, h4.w, acc[0][bb]);
+                acc[1][bb] = fmaf(wz.x, h4.x, acc[1][bb]); acc[1][bb] = fmaf(wz.y, h4.y, acc[1][bb]);
+                acc[1][bb] = fmaf(wz.z, h4.z, acc[1][bb]); acc[1][bb] = fmaf(wz.w, h4.w, acc[1][bb]);
+                acc[2][bb] = fmaf(wn.x, h4.x, acc[2][bb]); acc[2][bb] = fmaf(wn.y, h4.y, acc[2][bb]);
+                acc[2][bb] = fmaf(wn.z, h4.z, acc[2][bb]); acc[2][bb] = fmaf(wn.w, h4.w, acc[2][bb]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int bb = 0; bb < GRU_BW; ++bb) ps[((ks * GRU_BW + bb) * 3 + g) * GRU_H + u] = acc[g][bb];
+        __syncthreads();
+        float hr = bh_r, hz = bh_z, hn = bh_n;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            hr += ps[((s * GRU_BW + bme) * 3 + 0) * GRU_H + u];
+            hz += ps[((s * GRU_BW + bme) * 3 + 1) * GRU_H + u];
+            hn += ps[((s * GRU_BW + bme) * 3 + 2) * GRU_H + u];
+        }
+        const float r = sigmoidf_(gr + hr);
+        const float zg = sigmoidf_(gz + hz);
+        const float nn = tanhf(gn + r * hn);
+        const float hnew = (1.0f - zg) * nn + zg * hprev;
+        hprev = hnew;
+        hs[bme * GRU_H + u] = hnew;
+        if (bvalid) y[((size_t)(b0 + bme) * S + t) * 512 + dir * 256 + u] = hnew;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// attention pooling (models/models.py:63-64): scores = y a + b; softmax over time; ctx = sum_t w_t y_t
+// one workgroup per utterance, wave shuffles for the 512-wide dots
+// ------------------------------------------------------------------------------------------
+constexpr int ATT_MAX_S = 256;
+
+__global__ __launch_bounds__(256) void attention_pool_kernel(const float* __restrict__ y, const float* __restrict__ aw,
+                                                             const float* __restrict__ ab, float* __restrict__ ctx,
+                                                             int S) {
+    __shared__ float sc[ATT_MAX_S];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* yb = y + (size_t)b * S * 512;
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = aw[lane + 64 * i];
+    for (int t = wv; t < S; t += 4) {
+        float d = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d = fmaf(yb[(size_t)t * 512 + lane + 64 * i], a[i], d);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+        if (lane == 0) sc[t] = d + ab[0];
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = 0; t < S; ++t) mx = fmaxf(mx, sc[t]);
+    float den = 0.0f;
+    for (int t = 0; t < S; ++t) den += expf(sc[t] - mx);
+    for (int c = tid; c < 512; c += 256) {
+        float acc = 0.0f;
+        for (int t = 0; t < S; ++t) acc = fmaf(expf(sc[t] - mx) / den, yb[(size_t)t * 512 + c], acc);
+        ctx[(size_t)b * 512 + c] = acc;
+    }
+}
+
+// first index of the row maximum (torch.argmax / torch.max semantics on ties)
+__global__ void argmax_rows_kernel(const float* __restrict__ logits, long long* __restrict__ idx, int B, int C) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* r = logits + (size_t)b * C;
+    float best = r[0];
+    int bi = 0;
+    for (int c = 1; c < C; ++c)
+        if (r[c] > best) { best = r[c]; bi = c; }
+    idx[b] = bi;
+}

@@ -1,0 +1,77 @@
+// Internal declarations shared by the HIP translation units of libsir_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <vector>
+#include "sir_hip.h"
+
+#define SIR_WAVE 64               // CDNA wavefront width (hard-coded, see cdna guide section 1)
+#define SIR_NFFT 1024
+#define SIR_HOP 512
+#define SIR_NFREQ 513
+#define SIR_MAX_MELS 64
+#define SIR_FRAMES_PER_CHUNK 16   // frames handled by one workgroup of the frame kernel
+
+// kernels (or kernel groups) of the path, for sir_profile_*
+enum SirKernelId {
+    SIR_K_FEAT_FRAMES = 0, SIR_K_FEAT_NORM, SIR_K_PREP, SIR_K_CONV1, SIR_K_CONV2, SIR_K_CONV3,
+    SIR_K_GEMM_IH0, SIR_K_GRU0, SIR_K_GEMM_IH1, SIR_K_GRU1, SIR_K_ATTN, SIR_K_FC, SIR_K_COUNT
+};
+
+struct SirProfRec { int id; hipEvent_t e0, e1; };
+
+struct sir_handle {
+    // event profiling state (host only)
+    int prof_mode;      // 0 off, 1 every kernel, 2 only prof_only
+    int prof_only;
+    std::vector<SirProfRec> prof_pending;
+    std::vector<hipEvent_t> prof_free;
+    sir_feature_config cfg;
+    int device;
+    // feature tables (device)
+    float2* tw512;      // exp(-2*pi*i*j/512),  j = 0..511
+    float2* tw1024;     // exp(-2*pi*i*k/1024), k = 0..512
+    float* window;      // [1024]
+    float* melw;        // [max_taps][64]  tap-major, zero padded
+    int* mel_start;     // [64] first FFT bin of each filter
+    int max_taps;
+};
+
+void sir_set_error(const char* fmt, ...);
+int sir_check_hip(hipError_t e, const char* what);
+
+#define SIR_HIP_TRY(expr)                                   \
+    do {                                                    \
+        int _rc = sir_check_hip((expr), #expr);             \
+        if (_rc != SIR_OK) return _rc;                      \
+    } while (0)
+
+// RAII: records a HIP event pair on `st` around the launches issued while it is alive
+struct SirProfScope {
+    sir_handle* h; int id; hipStream_t st; hipEvent_t e0, e1; bool on;
+    SirProfScope(sir_handle* h_, int id_, hipStream_t st_) : h(h_), id(id_), st(st_), e0(nullptr), e1(nullptr) {
+        on = h->prof_mode == 1 || (h->prof_mode == 2 && h->prof_only == id);
+        if (!on) return;
+        hipEvent_t ev[2];
+        for (int i = 0; i < 2; ++i) {
+            if (!h->prof_free.empty()) { ev[i] = h->prof_free.back(); h->prof_free.pop_back(); }
+            else if (hipEventCreate(&ev[i]) != hipSuccess) { on = false; return; }
+        }
+        e0 = ev[0]; e1 = ev[1];
+        (void)hipEventRecord(e0, st);
+    }
+    ~SirProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(e1, st);
+        h->prof_pending.push_back(SirProfRec{id, e0, e1});
+    }
+};
+
+static inline size_t sir_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// features.hip
+int sir_features_launch(sir_handle* h, const void* wave, int wave_dtype, int64_t wave_stride,
+                        const int32_t* lengths, int batch, int max_len, float* out, int t_pad,
+                        float* db_out, void* workspace, size_t workspace_bytes, const sir_augment* aug,
+                        hipStream_t stream);
