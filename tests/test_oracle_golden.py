@@ -108,3 +108,13 @@ def test_fbank_vs_transformers_and_f64():
 def test_frame_counts():
     for n, t in ((16000, 32), (48000, 94), (80000, 157), (513, 2), (47999, 94)):
         assert features_ref.num_frames(n) == t
+
+
+def test_fast_ref_equals_explicit_forward(sd, model_golden):
+    """The fused-kernel form timed by bench.py's cpu_baseline is the same function."""
+    inp = cases.model_inputs()
+    fast = model_ref.FastRef(sd)
+    np.testing.assert_allclose(fast(inp["x_eval8"]).numpy(), model_golden["eval8_logits"], rtol=0, atol=2e-6)
+    sds = cases.sharp_head(sd, model_golden["sharp_fc_bias"])
+    lg = model_ref.FastRef(sds)(inp["x_sharp64"])
+    assert (lg.argmax(1).numpy() == model_golden["sharp64_argmax"]).all()
