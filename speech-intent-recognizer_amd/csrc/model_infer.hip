@@ -129,13 +129,13 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
         SirProfScope prof(h, SIR_K_CONV2, st);
         constexpr size_t lds = (size_t)(8 * 4 + 2) * (4 * 2 + 2) * 36 * 4;
         hipLaunchKernelGGL((conv3x3_mfma_kernel<32, 64, 4, 2, 0>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), lds, st, a1, wp2,
-                           bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2);
+                           bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
     }
     {
         SirProfScope prof(h, SIR_K_CONV3, st);
         constexpr size_t lds = (size_t)(8 * 2 + 2) * (4 * 4 + 2) * 36 * 4;
         hipLaunchKernelGGL((conv3x3_mfma_kernel<64, 128, 2, 4, 1>), dim3((d.wp2 + 15) / 16, 1, B), dim3(256), lds, st, a2, wp3,
-                           bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3);
+                           bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)nullptr);
     }
     SIR_KCHECK();
 
@@ -147,13 +147,14 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     hipLaunchKernelGGL(gemm_nt_bias_kernel, ggrid, dim3(256), 0, st, x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
                        w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024); }
     { SirProfScope prof(h, SIR_K_GRU0, st);
-    hipLaunchKernelGGL(gru_recurrence_kernel, rgrid, dim3(1024), 0, st, gi, wht, w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S); }
+    hipLaunchKernelGGL(gru_recurrence_kernel<false>, rgrid, dim3(1024), 0, st, gi, wht, w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S,
+                       (float*)nullptr); }
     { SirProfScope prof(h, SIR_K_GEMM_IH1, st);
     hipLaunchKernelGGL(gemm_nt_bias_kernel, ggrid, dim3(256), 0, st, y0, 512, w->gru_w_ih[2], w->gru_w_ih[3], 512,
                        w->gru_b_ih[2], w->gru_b_ih[3], gi, 1536, M, 768, 512); }
     { SirProfScope prof(h, SIR_K_GRU1, st);
-    hipLaunchKernelGGL(gru_recurrence_kernel, rgrid, dim3(1024), 0, st, gi, wht + (size_t)2 * 768 * 256, w->gru_b_hh[2],
-                       w->gru_b_hh[3], y1, B, S); }
+    hipLaunchKernelGGL(gru_recurrence_kernel<false>, rgrid, dim3(1024), 0, st, gi, wht + (size_t)2 * 768 * 256, w->gru_b_hh[2],
+                       w->gru_b_hh[3], y1, B, S, (float*)nullptr); }
     SIR_KCHECK();
 
     // ---- attention pooling + classifier head ------------------------------------------------

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void conv1_bn_relu_pool_kernel(
 template <int CIN, int COUT, int PR, int PC, int OUT_MODE>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
-    const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp) {
+    const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp,
+    float2* __restrict__ stats = nullptr) {
     constexpr int NT = COUT / 32, MT = 2, CK = 32, PS = CK + 4;
     constexpr int TR = 8 * PR, TC = 4 * PC, TROWS = TR + 2, TCOLS = TC + 2;
     static_assert(PR * PC == 8 && CIN % CK == 0, "tile shape");
@@ -182,6 +183,55 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
                 for (int nt = 0; nt < NT; ++nt) bcur[nt] = bnxt[nt];
             }
         }
+    }
+
+    if (OUT_MODE == 2) {
+        // raw epilogue (training forward / data gradient): store the un-normalised conv output at
+        // full resolution, NHWC, and optionally the per-channel (sum, sum of squares) of this
+        // workgroup's valid pixels for the batch-statistics BatchNorm (deterministic partials).
+        float ssum[NT], ssq[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { ssum[nt] = 0.0f; ssq[nt] = 0.0f; }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int xl = (r & 1) + 2 * kh, yl = ((r >> 1) & 1) + 2 * ((r >> 2) & 1) + 4 * ((r >> 3) & 1);
+                const int gy = ty0 + 8 * pr_[mt] + yl, gx = tx0 + 4 * pc_[mt] + xl;
+                if (gy < H && gx < W) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float v = acc[mt][nt][r];
+                        out[(((size_t)b * H + gy) * W + gx) * COUT + nt * 32 + m] = v;
+                        ssum[nt] += v;
+                        ssq[nt] = fmaf(v, v, ssq[nt]);
+                    }
+                }
+            }
+        if (stats) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                ssum[nt] += __shfl_xor(ssum[nt], 32);
+                ssq[nt] += __shfl_xor(ssq[nt], 32);
+            }
+            __syncthreads();                            // every wave is done reading the input tile
+            if (kh == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    lds[(wv * COUT + nt * 32 + m) * 2] = ssum[nt];
+                    lds[(wv * COUT + nt * 32 + m) * 2 + 1] = ssq[nt];
+                }
+            }
+            __syncthreads();
+            const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            for (int c = tid; c < COUT; c += 256) {
+                float s = 0.0f, q = 0.0f;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) { s += lds[(w4 * COUT + c) * 2]; q += lds[(w4 * COUT + c) * 2 + 1]; }
+                stats[blk * COUT + c] = make_float2(s, q);
+            }
+        }
+        return;
     }
 
     // epilogue: BN (folded) -> ReLU -> 2x2 max over registers 4q..4q+3 -> store
@@ -329,9 +379,12 @@ constexpr int GRU_H = 256, GRU_BW = 4;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// SAVE: also store (r, z, n, W_hn h + b_hn) per step for back-propagation through time,
+//   gates [B][S][2 dirs][4][256]
+template <bool SAVE>
 __global__ __launch_bounds__(1024) void gru_recurrence_kernel(
     const float* __restrict__ gi, const float* __restrict__ wt, const float* __restrict__ bhh0,
-    const float* __restrict__ bhh1, float* __restrict__ y, int B, int S) {
+    const float* __restrict__ bhh1, float* __restrict__ y, int B, int S, float* __restrict__ gates = nullptr) {
     __shared__ __attribute__((aligned(16))) float hs[GRU_BW * GRU_H];            // h[b][k]
     __shared__ float ps[4 * GRU_BW * 3 * GRU_H];                                  // partial[ks][b][gate*256+u]
     const int dir = blockIdx.y, b0 = blockIdx.x * GRU_BW;
@@ -390,7 +443,13 @@ __global__ __launch_bounds__(1024) void gru_recurrence_kernel(
         const float hnew = (1.0f - zg) * nn + zg * hprev;
         hprev = hnew;
         hs[bme * GRU_H + u] = hnew;
-        if (bvalid) y[((size_t)(b0 + bme) * S + t) * 512 + dir * 256 + u] = hnew;
+        if (bvalid) {
+            y[((size_t)(b0 + bme) * S + t) * 512 + dir * 256 + u] = hnew;
+            if (SAVE) {
+                float* gs = gates + (((size_t)(b0 + bme) * S + t) * 2 + dir) * 1024;
+                gs[u] = r; gs[256 + u] = zg; gs[512 + u] = nn; gs[768 + u] = hn;
+            }
+        }
         __syncthreads();
     }
 }

@@ -1,0 +1,666 @@
+// Training-only device kernels (forward pieces that differ from inference, backward, optimiser).
+// Included by model_train.hip.  Layouts as in model_kernels.h (NHWC activations).
+#pragma once
+#include "model_kernels.h"
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm with batch statistics
+// ------------------------------------------------------------------------------------------
+
+// conv1 is recomputed instead of stored (9 MACs per output): this pass only accumulates the
+// per-channel (sum, sum of squares) of the raw conv1 output over a 8 x 64 pixel tile.
+__global__ __launch_bounds__(256) void conv1_stats_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           float2* __restrict__ stats, int H, int W) {
+    __shared__ float tile[C1_TR * C1_TC];
+    __shared__ float red[8 * 32 * 2];
+    const int b = blockIdx.z, py0 = blockIdx.y * C1_PROWS, px0 = blockIdx.x * C1_PCOLS;
+    const int tid = threadIdx.x, c = tid & 31, slot = tid >> 5;
+    const float* xb = x + (size_t)b * H * W;
+    for (int i = tid; i < C1_TR * C1_TC; i += 256) {
+        const int ty = i / C1_TC, tx = i - ty * C1_TC;
+        const int gy = 2 * py0 - 1 + ty, gx = 2 * px0 - 1 + tx;
+        tile[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xb[(size_t)gy * W + gx] : 0.0f;
+    }
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
+    __syncthreads();
+    float s = 0.0f, q = 0.0f;
+    for (int i = 0; i < (C1_PROWS * C1_PCOLS) / 8; ++i) {
+        const int pp = slot + 8 * i, pyl = pp / C1_PCOLS, pxl = pp % C1_PCOLS;
+        float in[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) in[r][k] = tile[(2 * pyl + r) * C1_TC + 2 * pxl + k];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int gy = 2 * (py0 + pyl) + dy, gx = 2 * (px0 + pxl) + dx;
+                if (gy >= H || gx >= W) continue;
+                float a = 0.0f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) a = fmaf(in[dy + ky][dx + kx], wk[ky * 3 + kx], a);
+                s += a;
+                q = fmaf(a, a, q);
+            }
+    }
+    red[(slot * 32 + c) * 2] = s;
+    red[(slot * 32 + c) * 2 + 1] = q;
+    __syncthreads();
+    if (tid < 32) {
+        float ts = 0.0f, tq = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ts += red[(k * 32 + tid) * 2]; tq += red[(k * 32 + tid) * 2 + 1]; }
+        const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        stats[blk * 32 + tid] = make_float2(ts, tq);
+    }
+}
+
+// partial (sum, sumsq) [nblk][C] -> batch mean / biased var -> folded scale/shift for the forward,
+// saved mean / invstd for the backward, running statistics updated in place
+// (momentum 0.1, unbiased variance: torch.nn.BatchNorm2d training semantics).  One block per channel.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float2* __restrict__ stats, int nblk, int C, double count,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                           float momentum, float* __restrict__ scale,
+                                                           float* __restrict__ shift, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_invstd) {
+    __shared__ double rs[256], rq[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int i = tid; i < nblk; i += 256) {
+        const float2 v = stats[(size_t)i * C + c];
+        s += v.x;
+        q += v.y;
+    }
+    rs[tid] = s; rq[tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double mean = rs[0] / count;
+        double var = rq[0] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)SIR_BN_EPS));
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        save_mean[c] = (float)mean;
+        save_invstd[c] = invstd;
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mean;
+        run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// z (raw conv output, NHWC [B][H][W][C]) -> relu(bn(z)) -> 2x2 max-pool.
+// GRU_OUT = false: NHWC [B][Hp][Wp][C];  true: [B][Wp][C*Hp] with feature = c*Hp + py (models.py:55-57)
+template <bool GRU_OUT>
+__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* __restrict__ out,
+                                                            int B, int H, int W, int C, int Hp, int Wp) {
+    const int c4n = C / 4;
+    const size_t total = (size_t)B * Hp * Wp * c4n;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c4 = idx % c4n;
+        size_t rest = idx / c4n;
+        const int px = rest % Wp; rest /= Wp;
+        const int py = rest % Hp;
+        const int b = rest / Hp;
+        const float4 s = *reinterpret_cast<const float4*>(scale + c4 * 4);
+        const float4 t = *reinterpret_cast<const float4*>(shift + c4 * 4);
+        float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const float4 v = *reinterpret_cast<const float4*>(
+                    z + (((size_t)b * H + 2 * py + dy) * W + 2 * px + dx) * C + c4 * 4);
+                best.x = fmaxf(best.x, fmaf(v.x, s.x, t.x));
+                best.y = fmaxf(best.y, fmaf(v.y, s.y, t.y));
+                best.z = fmaxf(best.z, fmaf(v.z, s.z, t.z));
+                best.w = fmaxf(best.w, fmaf(v.w, s.w, t.w));
+            }
+        if (!GRU_OUT) {
+            *reinterpret_cast<float4*>(out + (((size_t)b * Hp + py) * Wp + px) * C + c4 * 4) = best;
+        } else {
+            float* o = out + ((size_t)b * Wp + px) * ((size_t)C * Hp) + (size_t)(c4 * 4) * Hp + py;
+            o[0] = best.x; o[Hp] = best.y; o[2 * Hp] = best.z; o[3 * Hp] = best.w;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// inter-layer GRU dropout (models.py:32, p = 0.5 in train()): counter-based keep mask, a pure
+// function of (seed, element index) so the backward pass regenerates it.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, size_t idx, float p) {
+    unsigned long long x = seed ^ (idx * 0x9E3779B97F4A7C15ull);
+    x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull; x ^= x >> 33;
+    return (float)(unsigned)(x >> 40) * (1.0f / 16777216.0f) >= p;
+}
+
+__global__ void dropout_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, float p,
+                               unsigned long long seed) {
+    const float sc = 1.0f / (1.0f - p);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = dropout_keep(seed, i, p) ? in[i] * sc : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// cross-entropy (mean) forward + gradient wrt logits:  loss = -mean_b log softmax(l_b)[y_b],
+// dlogits = (softmax - onehot) * grad_scale / B      (nn.CrossEntropyLoss(), train.py:242)
+// single workgroup, deterministic reduction
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                       int B, int C, float* __restrict__ loss, float* __restrict__ dlogits,
+                                                       float grad_scale) {
+    __shared__ float red[256];
+    float acc = 0.0f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* r = logits + (size_t)b * C;
+        float mx = r[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, r[c]);
+        float den = 0.0f;
+        for (int c = 0; c < C; ++c) den += expf(r[c] - mx);
+        const int y = (int)labels[b];
+        const float lse = mx + logf(den);
+        acc += lse - r[y];
+        if (dlogits) {
+            const float inv = 1.0f / den, gs = grad_scale / (float)B;
+            for (int c = 0; c < C; ++c)
+                dlogits[(size_t)b * C + c] = (expf(r[c] - mx) * inv - (c == y ? 1.0f : 0.0f)) * gs;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = red[0] / (float)B;
+}
+
+// ------------------------------------------------------------------------------------------
+// head backward: fc + attention pooling (models.py:63-67)
+//   dctx = dlogits fc_w;  w = softmax_t(y a + b);  dw_t = <dctx, y_t>;  ds_t = w_t (dw_t - sum w dw)
+//   dy_t = w_t dctx + ds_t a;  per-utterance partials of d attention.weight / d attention.bias
+// one workgroup per utterance
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ fcw,
+                                                        const float* __restrict__ y, const float* __restrict__ aw,
+                                                        const float* __restrict__ ab, float* __restrict__ dy,
+                                                        float* __restrict__ daw_part, float* __restrict__ dab_part,
+                                                        int S, int C) {
+    __shared__ float dctx[512];
+    __shared__ float sc[ATT_MAX_S], ds[ATT_MAX_S];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* yb = y + (size_t)b * S * 512;
+    for (int c = tid; c < 512; c += 256) {
+        float a = 0.0f;
+        for (int j = 0; j < C; ++j) a = fmaf(dlogits[(size_t)b * C + j], fcw[(size_t)j * 512 + c], a);
+        dctx[c] = a;
+    }
+    float a8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a8[i] = aw[lane + 64 * i];
+    __syncthreads();
+    for (int t = wv; t < S; t += 4) {
+        float d = 0.0f, g = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float yv = yb[(size_t)t * 512 + lane + 64 * i];
+            d = fmaf(yv, a8[i], d);
+            g = fmaf(yv, dctx[lane + 64 * i], g);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { d += __shfl_xor(d, o); g += __shfl_xor(g, o); }
+        if (lane == 0) { sc[t] = d + ab[0]; ds[t] = g; }          // ds holds dw_t for now
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = 0; t < S; ++t) mx = fmaxf(mx, sc[t]);
+    float den = 0.0f;
+    for (int t = 0; t < S; ++t) den += expf(sc[t] - mx);
+    float wdw = 0.0f;
+    for (int t = 0; t < S; ++t) wdw = fmaf(expf(sc[t] - mx) / den, ds[t], wdw);
+    __syncthreads();
+    for (int t = tid; t < S; t += 256) {
+        const float w = expf(sc[t] - mx) / den;
+        const float dst = w * (ds[t] - wdw);
+        sc[t] = w;                 // now the attention weight
+        ds[t] = dst;               // now d score
+    }
+    __syncthreads();
+    float dsum = 0.0f;
+    for (int t = 0; t < S; ++t) dsum += ds[t];
+    for (int c = tid; c < 512; c += 256) {
+        const float dc = dctx[c], ac = aw[c];
+        float da = 0.0f;
+        for (int t = 0; t < S; ++t) {
+            dy[((size_t)b * S + t) * 512 + c] = fmaf(sc[t], dc, ds[t] * ac);
+            da = fmaf(ds[t], yb[(size_t)t * 512 + c], da);
+        }
+        daw_part[(size_t)b * 512 + c] = da;
+    }
+    if (tid == 0) dab_part[b] = dsum;
+}
+
+// out[n] = sum_r in[r][n]   (deterministic column sums: bias / attention gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int rows, int ld, int n_cols,
+                                                      float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    float a = 0.0f;
+    if (col < n_cols)
+        for (int r = part; r < rows; r += 4) a += in[(size_t)r * ld + col];
+    red[part][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (part == 0 && col < n_cols) out[col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// dfc_w[j][c] = sum_b dlogits[b][j] ctx[b][c];  dfc_b[j] = sum_b dlogits[b][j]     (one block per class)
+__global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __restrict__ dlogits, const float* __restrict__ ctx,
+                                                        float* __restrict__ dw, float* __restrict__ db, int B, int C) {
+    const int j = blockIdx.x;
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        float a = 0.0f;
+        for (int b = 0; b < B; ++b) a = fmaf(dlogits[(size_t)b * C + j], ctx[(size_t)b * 512 + c], a);
+        dw[(size_t)j * 512 + c] = a;
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.0f;
+        for (int b = 0; b < B; ++b) s += dlogits[(size_t)b * C + j];
+        db[j] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// GRU back-propagation through time, one layer, both directions (mirror of gru_recurrence_kernel).
+//   dy    [B][S][512]  gradient wrt the layer output (both directions)
+//   gates [B][S][2][4][256] saved (r, z, n, W_hn h + b_hn);  y = layer output (h_prev = neighbour step)
+//   wr4   [2][192][256][4]  W_hh regrouped by 4 gate rows (prep_whh_bwd_kernel): lane = k
+//   dgi / dgh [B*S][1536]   gradients wrt the input-side / hidden-side gate pre-activations
+// Thread (u, b): gate math for hidden unit u of utterance b; thread (k, rs): partial of W_hh^T dgh
+// over gate rows [192 rs, 192 rs + 192).
+// ------------------------------------------------------------------------------------------
+__global__ void prep_whh_bwd_kernel(const float* __restrict__ w, float* __restrict__ wr4) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // over 768*256, layout [row/4][k][4]
+    if (idx >= 768 * 256) return;
+    const int e = idx & 3, k = (idx >> 2) & 255, r4 = idx >> 10;
+    wr4[idx] = w[(size_t)(r4 * 4 + e) * 256 + k];
+}
+
+__global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ gates,
+                                                        const float* __restrict__ y, const float* __restrict__ wr4,
+                                                        float* __restrict__ dgi, float* __restrict__ dgh, int B, int S) {
+    __shared__ __attribute__((aligned(16))) float gsh[GRU_BW * 768];       // dgh[b][row]
+    __shared__ float ps[4 * GRU_BW * GRU_H];                               // partial[rs][b][k]
+    const int dir = blockIdx.y, b0 = blockIdx.x * GRU_BW;
+    const int tid = threadIdx.x, u = tid & 255, ks = tid >> 8;
+    const int bme = ks;
+    const bool bvalid = (b0 + bme) < B;
+    const float4* w4 = reinterpret_cast<const float4*>(wr4) + (size_t)dir * 192 * 256;
+    float dh_carry = 0.0f;
+    for (int step = S - 1; step >= 0; --step) {
+        const int t = dir ? (S - 1 - step) : step;                // time index processed at `step`
+        const int tp = dir ? t + 1 : t - 1;                       // where h_prev lives (invalid at step 0)
+        float drp = 0.f, dzp = 0.f, dnp = 0.f, dnr = 0.f, dhz = 0.f;
+        if (bvalid) {
+            const size_t row = (size_t)(b0 + bme) * S + t;
+            const float* gs = gates + (row * 2 + dir) * 1024;
+            const float r = gs[u], zg = gs[256 + u], nn = gs[512 + u], hn = gs[768 + u];
+            const float hprev = (step > 0) ? y[((size_t)(b0 + bme) * S + tp) * 512 + dir * 256 + u] : 0.0f;
+            const float dh = dy[row * 512 + dir * 256 + u] + dh_carry;
+            const float dn = dh * (1.0f - zg);
+            const float dz = dh * (hprev - nn);
+            dnp = dn * (1.0f - nn * nn);
+            drp = dnp * hn * r * (1.0f - r);
+            dzp = dz * zg * (1.0f - zg);
+            dnr = dnp * r;
+            dhz = dh * zg;
+            float* gi_o = dgi + row * 1536 + dir * 768;
+            float* gh_o = dgh + row * 1536 + dir * 768;
+            gi_o[u] = drp; gi_o[256 + u] = dzp; gi_o[512 + u] = dnp;
+            gh_o[u] = drp; gh_o[256 + u] = dzp; gh_o[512 + u] = dnr;
+        }
+        gsh[bme * 768 + u] = drp; gsh[bme * 768 + 256 + u] = dzp; gsh[bme * 768 + 512 + u] = dnr;
+        __syncthreads();
+        float acc[GRU_BW];
+#pragma unroll
+        for (int bb = 0; bb < GRU_BW; ++bb) acc[bb] = 0.0f;
+#pragma unroll 4
+        for (int r4 = ks * 48; r4 < ks * 48 + 48; ++r4) {
+            const float4 wv = w4[(size_t)r4 * 256 + u];
+#pragma unroll
+            for (int bb = 0; bb < GRU_BW; ++bb) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gsh + bb * 768 + r4 * 4);
+                acc[bb] = fmaf(wv.x, g4.x, acc[bb]); acc[bb] = fmaf(wv.y, g4.y, acc[bb]);
+                acc[bb] = fmaf(wv.z, g4.z, acc[bb]); acc[bb] = fmaf(wv.w, g4.w, acc[bb]);
+            }
+        }
+#pragma unroll
+        for (int bb = 0; bb < GRU_BW; ++bb) ps[(ks * GRU_BW + bb) * GRU_H + u] = acc[bb];
+        __syncthreads();
+        dh_carry = dhz + ps[(0 * GRU_BW + bme) * GRU_H + u] + ps[(1 * GRU_BW + bme) * GRU_H + u] +
+                   ps[(2 * GRU_BW + bme) * GRU_H + u] + ps[(3 * GRU_BW + bme) * GRU_H + u];
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// General fp32-MFMA GEMM for the backward pass.
+//   C[m][n] (+)= sum_k opA(m,k) * opB(k,n)
+//   A_KM = false: A is [M][lda] (k contiguous)      true: A is [K][lda] (m contiguous)
+//   B_KN = false: B is [N][ldb] (k contiguous)      true: B is [K][ldb] (n contiguous)
+//   split-K over blockIdx.z: slab z covers k in [z*kchunk, (z+1)*kchunk) and is written to
+//   C + z*slab_stride (deterministic partial slabs, summed by slab_reduce_kernel), or, with
+//   gridDim.z == 1, directly to C.
+//   B2/ksplit: rows k >= ksplit of a k-major B come from B2 (two stacked weight matrices).
+//   seq/shift (B_KN only): row k of B is taken from row k+shift of the same length-`seq` sequence,
+//   zero outside it (the h_{t-1} / h_{t+1} operand of the W_hh gradient).
+// 128 x 64 tile, BK = 32, 4 waves 2x2, wave tile 64 x 32.
+// ------------------------------------------------------------------------------------------
+template <bool A_KM, bool B_KN>
+__global__ __launch_bounds__(256) void gemm_general_kernel(const float* __restrict__ A, int lda,
+                                                            const float* __restrict__ B, const float* __restrict__ B2,
+                                                            int ksplit, int ldb, float* __restrict__ C, int ldc,
+                                                            size_t slab_stride, int M, int N, int K, int kchunk, int seq,
+                                                            int shift) {
+    constexpr int SA = A_KM ? (GB_M + 4) : GB_S;         // LDS row stride of the A tile
+    constexpr int SB = B_KN ? (GB_N + 4) : GB_S;
+    __shared__ __attribute__((aligned(16))) float As[A_KM ? GB_K * SA : GB_M * SA];
+    __shared__ __attribute__((aligned(16))) float Bs[B_KN ? GB_K * SB : GB_N * SB];
+    const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
+    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1, m = lane & 31, kh = lane >> 5;
+
+    float4 ra[4], rb[2];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            if (!A_KM) {
+                const int row = idx >> 3, c4 = idx & 7;          // [128 m][8 x float4 of k]
+                const int k = k0 + c4 * 4;
+                ra[i] = (m0 + row < M && k < kend) ? *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * lda + k)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const int kr = idx >> 5, c4 = idx & 31;          // [32 k][32 x float4 of m]
+                const int k = k0 + kr, mm = m0 + c4 * 4;
+                ra[i] = (k < kend && mm < M) ? *reinterpret_cast<const float4*>(A + (size_t)k * lda + mm)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            if (!B_KN) {
+                const int row = idx >> 3, c4 = idx & 7;          // [64 n][8 x float4 of k]
+                const int k = k0 + c4 * 4;
+                rb[i] = (n0 + row < N && k < kend) ? *reinterpret_cast<const float4*>(B + (size_t)(n0 + row) * ldb + k)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const int kr = idx >> 4, c4 = idx & 15;          // [32 k][16 x float4 of n]
+                int k = k0 + kr;
+                const int nn = n0 + c4 * 4;
+                bool ok = k < kend && nn < N;
+                const float* src = B;
+                if (seq > 0) {
+                    const int t = k % seq + shift;
+                    ok = ok && t >= 0 && t < seq;
+                    k += shift;
+                } else if (B2 && k >= ksplit) {
+                    src = B2;
+                    k -= ksplit;
+                }
+                rb[i] = ok ? *reinterpret_cast<const float4*>(src + (size_t)k * ldb + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            if (!A_KM) *reinterpret_cast<float4*>(As + (idx >> 3) * SA + (idx & 7) * 4) = ra[i];
+            else *reinterpret_cast<float4*>(As + (idx >> 5) * SA + (idx & 31) * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            if (!B_KN) *reinterpret_cast<float4*>(Bs + (idx >> 3) * SB + (idx & 7) * 4) = rb[i];
+            else *reinterpret_cast<float4*>(Bs + (idx >> 4) * SB + (idx & 15) * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+
+    if (kbeg < kend) {
+        load_tile(kbeg);
+        store_tile();
+        __syncthreads();
+        for (int k0 = kbeg; k0 < kend; k0 += GB_K) {
+            const bool more = k0 + GB_K < kend;
+            if (more) load_tile(k0 + GB_K);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                float a0[4], a1[4], bq[4];
+                if (!A_KM) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(As + (wm * 64 + m) * SA + kk * 8 + kh * 4);
+                    const float4 v1 = *reinterpret_cast<const float4*>(As + (wm * 64 + 32 + m) * SA + kk * 8 + kh * 4);
+                    a0[0] = v0.x; a0[1] = v0.y; a0[2] = v0.z; a0[3] = v0.w;
+                    a1[0] = v1.x; a1[1] = v1.y; a1[2] = v1.z; a1[3] = v1.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        a0[i] = As[(kk * 8 + kh * 4 + i) * SA + wm * 64 + m];
+                        a1[i] = As[(kk * 8 + kh * 4 + i) * SA + wm * 64 + 32 + m];
+                    }
+                }
+                if (!B_KN) {
+                    const float4 v = *reinterpret_cast<const float4*>(Bs + (wn * 32 + m) * SB + kk * 8 + kh * 4);
+                    bq[0] = v.x; bq[1] = v.y; bq[2] = v.z; bq[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bq[i] = Bs[(kk * 8 + kh * 4 + i) * SB + wn * 32 + m];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], bq[i], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], bq[i], acc[1], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            if (more) {
+                store_tile();
+                __syncthreads();
+            }
+        }
+    }
+    float* Cz = C + (size_t)blockIdx.z * slab_stride;
+    const int n = n0 + wn * 32 + m;
+    if (n < N) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < M) Cz[(size_t)row * ldc + n] = acc[mt][r];
+            }
+    }
+}
+
+// out[i] = sum_z slabs[z][i]
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, size_t slab_stride, int nslab, size_t n,
+                                   float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float a = 0.0f;
+        for (int z = 0; z < nslab; ++z) a += slabs[(size_t)z * slab_stride + i];
+        out[i] = a;
+    }
+}
+
+// a[i] += b[i]  /  a[i] = a[i]*mask  helpers for the layer-0 dropout backward
+__global__ void dropout_bwd_kernel(float* __restrict__ g, size_t n, float p, unsigned long long seed) {
+    const float sc = 1.0f / (1.0f - p);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        g[i] = dropout_keep(seed, i, p) ? g[i] * sc : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward through max-pool -> ReLU -> BatchNorm (batch statistics).
+//   da: gradient wrt the pooled output (NHWC [B][Hp][Wp][C], or the GRU layout when GRU_IN)
+//   z : raw conv output [B][H][W][C];  y = z*scale+shift
+//   dy(pixel) = da if the pixel is the first maximum of its 2x2 window and y > 0, else 0
+// pass 1 (bn_bwd_reduce): per-block partial sums of dy and dy*xhat per channel (-> dbeta, dgamma)
+// pass 2 (bn_bwd_dz): dz = gamma*invstd*(dy - mean(dy) - xhat*mean(dy*xhat)) at full resolution
+// ------------------------------------------------------------------------------------------
+template <bool GRU_IN>
+__device__ __forceinline__ float4 load_da4(const float* __restrict__ da, int b, int py, int px, int c4, int Hp, int Wp,
+                                           int C) {
+    if (!GRU_IN) return *reinterpret_cast<const float4*>(da + (((size_t)b * Hp + py) * Wp + px) * C + c4 * 4);
+    const float* o = da + ((size_t)b * Wp + px) * ((size_t)C * Hp) + (size_t)(c4 * 4) * Hp + py;
+    return make_float4(o[0], o[Hp], o[2 * Hp], o[3 * Hp]);
+}
+
+// gradient reaching pixel (dy,dx) of the window, per channel component
+__device__ __forceinline__ float route1(float y00, float y01, float y10, float y11, int pos, float g) {
+    float best = y00; int arg = 0;
+    if (y01 > best) { best = y01; arg = 1; }
+    if (y10 > best) { best = y10; arg = 2; }
+    if (y11 > best) { best = y11; arg = 3; }
+    return (arg == pos && best > 0.0f) ? g : 0.0f;
+}
+
+template <bool GRU_IN>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ z, const float* __restrict__ da,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             float2* __restrict__ part, int B, int H, int W, int C, int Hp,
+                                                             int Wp, int pix_per_block) {
+    // block = (channel group of 64 lanes x 4 pixel lanes); loops over `pix_per_block` pooled pixels
+    __shared__ float rs[256], rq[256];
+    const int c4n = C / 4;                                // float4 groups per pixel
+    const int lanes_c = c4n < 64 ? c4n : 64;              // threads along channels
+    const int pl = 256 / lanes_c;                         // pixel lanes
+    const int c4 = threadIdx.x % lanes_c, pslot = threadIdx.x / lanes_c;
+    const size_t npix = (size_t)B * Hp * Wp;
+    const size_t p0 = (size_t)blockIdx.x * pix_per_block;
+    float4 sdy = make_float4(0.f, 0.f, 0.f, 0.f), sdx = sdy;
+    for (int cc = c4; cc < c4n; cc += lanes_c) {
+        const float4 s = *reinterpret_cast<const float4*>(scale + cc * 4), t = *reinterpret_cast<const float4*>(shift + cc * 4);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + cc * 4), is = *reinterpret_cast<const float4*>(invstd + cc * 4);
+        for (int i = pslot; i < pix_per_block; i += pl) {
+            const size_t p = p0 + i;
+            if (p >= npix) break;
+            const int px = p % Wp, py = (p / Wp) % Hp, b = p / ((size_t)Wp * Hp);
+            const float4 g = load_da4<GRU_IN>(da, b, py, px, cc, Hp, Wp, C);
+            float4 zz[4], yy[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                zz[q] = *reinterpret_cast<const float4*>(z + (((size_t)b * H + 2 * py + (q >> 1)) * W + 2 * px + (q & 1)) * C + cc * 4);
+                yy[q] = make_float4(fmaf(zz[q].x, s.x, t.x), fmaf(zz[q].y, s.y, t.y), fmaf(zz[q].z, s.z, t.z), fmaf(zz[q].w, s.w, t.w));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float dx_ = route1(yy[0].x, yy[1].x, yy[2].x, yy[3].x, q, g.x);
+                const float dy_ = route1(yy[0].y, yy[1].y, yy[2].y, yy[3].y, q, g.y);
+                const float dz_ = route1(yy[0].z, yy[1].z, yy[2].z, yy[3].z, q, g.z);
+                const float dw_ = route1(yy[0].w, yy[1].w, yy[2].w, yy[3].w, q, g.w);
+                sdy.x += dx_; sdy.y += dy_; sdy.z += dz_; sdy.w += dw_;
+                sdx.x = fmaf(dx_, (zz[q].x - mu.x) * is.x, sdx.x); sdx.y = fmaf(dy_, (zz[q].y - mu.y) * is.y, sdx.y);
+                sdx.z = fmaf(dz_, (zz[q].z - mu.z) * is.z, sdx.z); sdx.w = fmaf(dw_, (zz[q].w - mu.w) * is.w, sdx.w);
+            }
+        }
+        // reduce over the pixel lanes for this channel group, component by component
+        const float vs[4] = {sdy.x, sdy.y, sdy.z, sdy.w}, vq[4] = {sdx.x, sdx.y, sdx.z, sdx.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __syncthreads();
+            rs[threadIdx.x] = vs[e]; rq[threadIdx.x] = vq[e];
+            __syncthreads();
+            if (pslot == 0) {
+                float a = 0.0f, q2 = 0.0f;
+                for (int k = 0; k < pl; ++k) { a += rs[k * lanes_c + c4]; q2 += rq[k * lanes_c + c4]; }
+                part[(size_t)blockIdx.x * C + cc * 4 + e] = make_float2(a, q2);
+            }
+        }
+        sdy = make_float4(0.f, 0.f, 0.f, 0.f); sdx = sdy;
+    }
+}
+
+// sums the (sum dy, sum dy*xhat) partials -> dbeta, dgamma and the two per-channel means used by dz
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float2* __restrict__ part, int nblk, int C, double count,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ mdy, float* __restrict__ mdyx) {
+    __shared__ double rs[256], rq[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int i = tid; i < nblk; i += 256) { const float2 v = part[(size_t)i * C + c]; s += v.x; q += v.y; }
+    rs[tid] = s; rq[tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        dbeta[c] = (float)rs[0];
+        dgamma[c] = (float)rq[0];
+        mdy[c] = (float)(rs[0] / count);
+        mdyx[c] = (float)(rq[0] / count);
+    }
+}
+
+template <bool GRU_IN>
+__global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const float* __restrict__ z, const float* __restrict__ da,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ mdy, const float* __restrict__ mdyx,
+                                                         float* __restrict__ dz, int B, int H, int W, int C, int Hp, int Wp) {
+    const int c4n = C / 4;
+    const size_t total = (size_t)B * H * W * c4n;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int cc = idx % c4n;
+        size_t rest = idx / c4n;
+        const int x = rest % W; rest /= W;
+        const int yy_ = rest % H;
+        const int b = rest / H;
+        const float4 s = *reinterpret_cast<const float4*>(scale + cc * 4), t = *reinterpret_cast<const float4*>(shift + cc * 4);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + cc * 4), is = *reinterpret_cast<const float4*>(invstd + cc * 4);
+        const float4 m1 = *reinterpret_cast<const float4*>(mdy + cc * 4), m2 = *reinterpret_cast<const float4*>(mdyx + cc * 4);
+        const float4 zc = *reinterpret_cast<const float4*>(z + (((size_t)b * H + yy_) * W + x) * C + cc * 4);
+        float4 dyv = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int py = yy_ >> 1, px = x >> 1;
+        if (py < Hp && px < Wp) {
+            const float4 g = load_da4<GRU_IN>(da, b, py, px, cc, Hp, Wp, C);
+            float4 yv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 zq = *reinterpret_cast<const float4*>(z + (((size_t)b * H + 2 * py + (q >> 1)) * W + 2 * px + (q & 1)) * C + cc * 4);
+                yv[q] = make_float4(fmaf(zq.x, s.x, t.x), fmaf(zq.y, s.y, t.y), fmaf(zq.z, s.z, t.z), fmaf(zq.w, s.w, t.w));
+            }
+            const int pos = ((yy_ & 1) << 1) | (x & 1);
+            dyv.x = route1(yv[0].x, yv[1].x, yv[2].x, yv[3].x, pos, g.x);
+            dyv.y = route1(yv[0].y, yv[1].y, yv[2].y, yv[3].y, pos, g.y);
+            dyv.z = route1(yv[0].z, yv[1].z, yv[2].z, yv[3].z, pos, g.z);
+            dyv.w = route1(yv[0].w, yv[1].w, yv[2].w, yv[3].w, pos, g.w);
+        }
+        float4 o;
+        o.x = s.x * (dyv.x - m1.x - (zc.x - mu.x) * is.x * m2.x);
+        o.y = s.y * (dyv.y - m1.y - (zc.y - mu.y) * is.y * m2.y);
+        o.z = s.z * (dyv.z - m1.z - (zc.z - mu.z) * is.z * m2.z);
+        o.w = s.w * (dyv.w - m1.w - (zc.w - mu.w) * is.w * m2.w);
+        *reinterpret_cast<float4*>(dz + (((size_t)b * H + yy_) * W + x) * C + cc * 4) = o;
+    }
+}
