@@ -131,6 +131,54 @@ int sir_model_infer(sir_handle* h, const sir_model_weights* w, const float* feat
                     int t_frames, float* logits, int64_t* argmax, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* ---- training step ----------------------------------------------------------------------------
+ * Replaces the body of train_epoch (scripts/train.py:90-107): model(mel) in train() mode,
+ * criterion(output, label), loss.backward(), optimizer.step().
+ * Gradients are written (not accumulated) to the device pointers of sir_model_grads, which mirror
+ * the parameter pointers of sir_model_weights (the BN running statistics have no gradient). */
+typedef struct sir_model_grads {
+    float* conv_w[3];
+    float* bn_w[3];
+    float* bn_b[3];
+    float* gru_w_ih[4];
+    float* gru_w_hh[4];
+    float* gru_b_ih[4];
+    float* gru_b_hh[4];
+    float* attn_w;
+    float* attn_b;
+    float* fc_w;
+    float* fc_b;
+} sir_model_grads;
+
+/* Training-mode forward (models/models.py:41-68 under model.train()): BatchNorm uses batch
+ * statistics and updates bn_running_mean/var IN PLACE (momentum, unbiased variance); the inter-layer
+ * GRU dropout (models.py:32) uses a counter-based mask keyed by dropout_seed (dropout_p = 0 turns it
+ * off); activations needed by the backward pass stay in `workspace`
+ * (sir_model_workspace_bytes(h, batch, t_frames, 1) bytes), which must be handed unchanged to
+ * sir_model_train_bwd. */
+int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, float* const bn_running_mean[3],
+                        float* const bn_running_var[3], const float* feats, int batch, int t_frames,
+                        float bn_momentum, float dropout_p, uint64_t dropout_seed, float* logits,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* nn.CrossEntropyLoss() (mean) of train.py:242/105: loss[0] = -mean log softmax(logits)[label];
+ * dlogits (optional) = d loss / d logits * grad_scale. */
+int sir_ce_loss(sir_handle* h, const float* logits, const int64_t* labels, int batch, int num_classes,
+                float* loss, float* dlogits, float grad_scale, void* stream);
+
+/* loss.backward() (train.py:106): all 29 parameter gradients from dlogits and the saved workspace. */
+int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, const float* feats, const float* dlogits,
+                        int batch, int t_frames, float dropout_p, uint64_t dropout_seed,
+                        const sir_model_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
+int sir_model_train_workspace_offsets(const sir_handle* h, int batch, int t_frames, size_t* offsets, int n);
+
+/* optimizer.step() for torch.optim.Adam(lr, betas, eps, weight_decay) with coupled L2
+ * (train.py:246-250, :107): one multi-tensor launch.  The pointer arrays are HOST arrays of device
+ * pointers (n_tensors <= 32); `step` is the 1-based step count used for bias correction. */
+int sir_adam_step(sir_handle* h, int n_tensors, float* const* params, const float* const* grads,
+                  float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes, int step,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 /* ---- measurement -----------------------------------------------------------------------------
  * HIP-event timing of the kernels of the path, recorded on the stream they are launched on
  * (bench.py's roofline figures come from here).  mode 0 = off, 1 = every kernel, 2 = only

@@ -114,15 +114,27 @@ def forward(sd, x, train=False, new_stats=None, dropout_mask=None, stages=None):
     return ctx @ sd["fc.weight"].t() + sd["fc.bias"]
 
 
-def loss_and_grads(sd, x, labels, dropout_mask=None):
-    """One training-mode forward/backward (CE mean).  Returns loss, grads{key}, new BN stats, logits."""
+def loss_and_grads(sd, x, labels, dropout_mask=None, stages=None):
+    """One training-mode forward/backward (CE mean).  Returns loss, grads{key}, new BN stats, logits.
+    With ``stages`` (a dict) the intermediate activations are stored under their names and their
+    gradients under ``"d_" + name`` (for stage-level checks of the HIP backward)."""
     params = {k: sd[k].detach().clone().requires_grad_(True) for k in PARAM_KEYS}
     full = dict(sd)
     full.update(params)
     new_stats = {}
-    logits = forward(full, x, train=True, new_stats=new_stats, dropout_mask=dropout_mask)
+    logits = forward(full, x, train=True, new_stats=new_stats, dropout_mask=dropout_mask, stages=stages)
+    if stages is not None:
+        for t in stages.values():
+            t.retain_grad()
     loss = F.cross_entropy(logits, labels)
-    grads = torch.autograd.grad(loss, [params[k] for k in PARAM_KEYS])
+    grads = torch.autograd.grad(loss, [params[k] for k in PARAM_KEYS], retain_graph=stages is not None)
+    if stages is not None:
+        names = list(stages)
+        inter = torch.autograd.grad(loss, [stages[n] for n in names], allow_unused=True)
+        for n, g in zip(names, inter):
+            stages["d_" + n] = g
+        for n in names:
+            stages[n] = stages[n].detach()
     return loss.detach(), dict(zip(PARAM_KEYS, grads)), new_stats, logits.detach()
 
 

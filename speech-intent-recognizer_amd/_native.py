@@ -36,6 +36,13 @@ class ModelWeights(C.Structure):
                 ("num_classes", C.c_int)]
 
 
+class ModelGrads(C.Structure):
+    _fields_ = [("conv_w", C.c_void_p * 3), ("bn_w", C.c_void_p * 3), ("bn_b", C.c_void_p * 3),
+                ("gru_w_ih", C.c_void_p * 4), ("gru_w_hh", C.c_void_p * 4),
+                ("gru_b_ih", C.c_void_p * 4), ("gru_b_hh", C.c_void_p * 4),
+                ("attn_w", C.c_void_p), ("attn_b", C.c_void_p), ("fc_w", C.c_void_p), ("fc_b", C.c_void_p)]
+
+
 # name -> (restype, argtypes); must list every function declared in include/sir_hip.h
 SIGNATURES = {
     "sir_abi_version": (C.c_int, []),
@@ -50,6 +57,17 @@ SIGNATURES = {
     "sir_model_workspace_offsets": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.c_int]),
     "sir_model_infer": (C.c_int, [C.c_void_p, C.POINTER(ModelWeights), C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sir_model_train_fwd": (C.c_int, [C.c_void_p, C.POINTER(ModelWeights), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                      C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p,
+                                      C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sir_ce_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                              C.c_void_p]),
+    "sir_model_train_bwd": (C.c_int, [C.c_void_p, C.POINTER(ModelWeights), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_float, C.c_uint64, C.POINTER(ModelGrads), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sir_model_train_workspace_offsets": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.c_int]),
+    "sir_adam_step": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_float, C.c_float, C.c_float,
+                                C.c_float, C.c_float, C.c_void_p]),
     "sir_profile_kernel_count": (C.c_int, []),
     "sir_profile_kernel_name": (C.c_char_p, [C.c_int]),
     "sir_profile_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

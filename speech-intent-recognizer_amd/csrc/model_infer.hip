@@ -57,7 +57,8 @@ size_t ws_layout(const Dims& d, size_t* off) {
 }  // namespace
 
 extern "C" size_t sir_model_workspace_bytes(const sir_handle* h, int batch, int t_frames, int train) {
-    (void)h; (void)train;
+    (void)h;
+    if (train) return sir_train_workspace_bytes_impl(batch, t_frames);
     Dims d;
     if (!make_dims(batch, t_frames, &d)) return 0;
     size_t off[WS_COUNT];

@@ -21,7 +21,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // conv weight [COUT][CIN][3][3] -> wp[g][co][8], g = (ci/8)*9 + tap, e = ci%8: one wave-load of
 // the B operand (32 output channels x 8 input channels of one tap) is 1 KiB contiguous.
-__global__ void prep_conv_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int cin, int cout) {
+static __global__ void prep_conv_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int cin, int cout) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = cin * 9 * cout;
     if (idx >= total) return;
@@ -31,7 +31,7 @@ __global__ void prep_conv_w_kernel(const float* __restrict__ w, float* __restric
 }
 
 // eval-mode BatchNorm folded to y = x*scale + shift (models/models.py:50-52, running stats)
-__global__ void prep_bn_kernel(const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ mean,
+static __global__ void prep_bn_kernel(const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ mean,
                                const float* __restrict__ var, float* __restrict__ scale, float* __restrict__ shift, int c) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c) return;
@@ -41,7 +41,7 @@ __global__ void prep_bn_kernel(const float* __restrict__ g, const float* __restr
 }
 
 // W_hh [768][256] (k contiguous) -> wt[k/4][768][4]: lane = gate row, one 16-byte load carries 4 k
-__global__ void prep_whh_kernel(const float* __restrict__ w, float* __restrict__ wt) {
+static __global__ void prep_whh_kernel(const float* __restrict__ w, float* __restrict__ wt) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // over 768*256
     if (idx >= 768 * 256) return;
     const int e = idx & 3, row = (idx >> 2) % 768, k4 = (idx >> 2) / 768;
@@ -55,7 +55,7 @@ __global__ void prep_whh_kernel(const float* __restrict__ w, float* __restrict__
 constexpr int C1_PROWS = 4, C1_PCOLS = 32;          // pooled pixels per block: 4 x 32
 constexpr int C1_TR = 2 * C1_PROWS + 2, C1_TC = 2 * C1_PCOLS + 2;
 
-__global__ __launch_bounds__(256) void conv1_bn_relu_pool_kernel(
+static __global__ __launch_bounds__(256) void conv1_bn_relu_pool_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp) {
     __shared__ float tile[C1_TR * C1_TC];
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 // ------------------------------------------------------------------------------------------
 constexpr int GB_M = 128, GB_N = 64, GB_K = 32, GB_S = GB_K + 4;
 
-__global__ __launch_bounds__(256) void gemm_nt_bias_kernel(
+static __global__ __launch_bounds__(256) void gemm_nt_bias_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ B0, const float* __restrict__ B1, int ldb,
     const float* __restrict__ bias0, const float* __restrict__ bias1, float* __restrict__ C, int ldc,
     int M, int N, int K) {
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(1024) void gru_recurrence_kernel(
 // ------------------------------------------------------------------------------------------
 constexpr int ATT_MAX_S = 256;
 
-__global__ __launch_bounds__(256) void attention_pool_kernel(const float* __restrict__ y, const float* __restrict__ aw,
+static __global__ __launch_bounds__(256) void attention_pool_kernel(const float* __restrict__ y, const float* __restrict__ aw,
                                                              const float* __restrict__ ab, float* __restrict__ ctx,
                                                              int S) {
     __shared__ float sc[ATT_MAX_S];
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void attention_pool_kernel(const float* __rest
 }
 
 // first index of the row maximum (torch.argmax / torch.max semantics on ties)
-__global__ void argmax_rows_kernel(const float* __restrict__ logits, long long* __restrict__ idx, int B, int C) {
+static __global__ void argmax_rows_kernel(const float* __restrict__ logits, long long* __restrict__ idx, int B, int C) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const float* r = logits + (size_t)b * C;

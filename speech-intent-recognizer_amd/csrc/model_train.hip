@@ -1,0 +1,424 @@
+// Training step of CNNAudioGRU on MI355X: forward with batch-statistics BatchNorm and saved
+// activations (sir_model_train_fwd), cross-entropy (sir_ce_loss), full backward
+// (sir_model_train_bwd) and multi-tensor Adam (sir_adam_step).  Replaces the body of
+// train_epoch (scripts/train.py:90-107: forward, criterion, loss.backward(), optimizer.step()).
+#include "train_kernels.h"
+
+namespace {
+
+enum TrainBuf {
+    TB_A1 = 0, TB_Z2, TB_A2, TB_Z3, TB_X0, TB_GI, TB_G0, TB_G1, TB_Y0, TB_Y0D, TB_Y1, TB_CTX,
+    TB_BN,        // [4][224]: scale, shift, mean, invstd (bn1|bn2|bn3 channel ranges 0,32,96)
+    TB_BNB,       // [2][224]: mean dy, mean dy*xhat (backward)
+    TB_STATS,     // float2 partials for BN forward/backward reductions
+    TB_WP2, TB_WP3, TB_WHT, TB_WR4, TB_WP2T, TB_WP3T,
+    TB_DY1, TB_DY0, TB_DGI, TB_DGH, TB_DX0, TB_DZ3, TB_DA2, TB_DZ2, TB_DA1,
+    TB_SMALL,     // daw_part [B][512], dab_part [B], conv1 wgrad partials
+    TB_SLAB,      // split-K / wgrad partial slabs
+    TB_COUNT
+};
+
+struct TDims {
+    int B, T, wp1, wp2, wp3, S;
+    int c1gx, c1gy;          // conv1 grids (ceil over un-pooled odd columns)
+    int c2gx, c3gx;
+    int wg2_blocks, wg3_blocks, wg2_rb, wg3_rb;
+    int ksplits, kchunk;
+};
+
+bool make_tdims(int batch, int t, TDims* d) {
+    d->B = batch; d->T = t;
+    d->wp1 = t / 2; d->wp2 = d->wp1 / 2; d->wp3 = d->wp2 / 2; d->S = d->wp3;
+    if (!(batch > 0 && d->S >= 1 && d->S <= ATT_MAX_S && batch <= 65535)) return false;
+    d->c1gx = ((t + 1) / 2 + C1_PCOLS - 1) / C1_PCOLS;
+    d->c1gy = (32 + C1_PROWS - 1) / C1_PROWS;
+    d->c2gx = (d->wp1 + 7) / 8;
+    d->c3gx = (d->wp2 + 15) / 16;
+    d->wg2_rb = 16; d->wg3_rb = 8;                     // rows per workgroup of the weight-gradient kernels
+    d->wg2_blocks = batch * (32 / d->wg2_rb);
+    d->wg3_blocks = batch * (16 / d->wg3_rb);
+    const int K = batch * d->S;
+    d->ksplits = K >= 2048 ? 8 : (K >= 256 ? 2 : 1);
+    d->kchunk = ((K + d->ksplits - 1) / d->ksplits + 31) / 32 * 32;
+    return true;
+}
+
+void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
+    const size_t B = d.B, S = d.S;
+    n[TB_A1] = B * 32 * d.wp1 * 32;
+    n[TB_Z2] = B * 32 * d.wp1 * 64;
+    n[TB_A2] = B * 16 * d.wp2 * 64;
+    n[TB_Z3] = B * 16 * d.wp2 * 128;
+    n[TB_X0] = B * S * 1024;
+    n[TB_GI] = B * S * 1536;
+    n[TB_G0] = B * S * 2048;
+    n[TB_G1] = B * S * 2048;
+    n[TB_Y0] = B * S * 512;
+    n[TB_Y0D] = B * S * 512;
+    n[TB_Y1] = B * S * 512;
+    n[TB_CTX] = B * 512;
+    n[TB_BN] = 4 * 224;
+    n[TB_BNB] = 2 * 224;
+    size_t st = (size_t)d.c1gx * d.c1gy * B * 32;                       // conv1 partials (float2)
+    const size_t s2 = (size_t)d.c2gx * B * 64, s3 = (size_t)d.c3gx * B * 128;
+    if (s2 > st) st = s2;
+    if (s3 > st) st = s3;
+    const size_t bw = (size_t)(B * 16 * d.wp1 / 64 + 64) * 128;          // bn backward partials, generous
+    if (bw > st) st = bw;
+    n[TB_STATS] = 2 * st;
+    n[TB_WP2] = 36 * 64 * 8;
+    n[TB_WP3] = 72 * 128 * 8;
+    n[TB_WHT] = 4 * 768 * 256;
+    n[TB_WR4] = 4 * 768 * 256;
+    n[TB_WP2T] = 72 * 32 * 8;
+    n[TB_WP3T] = 144 * 64 * 8;
+    n[TB_DY1] = B * S * 512;
+    n[TB_DY0] = B * S * 512;
+    n[TB_DGI] = B * S * 1536;
+    n[TB_DGH] = B * S * 1536;
+    n[TB_DX0] = B * S * 1024;
+    n[TB_DZ3] = n[TB_Z3];
+    n[TB_DA2] = n[TB_A2];
+    n[TB_DZ2] = n[TB_Z2];
+    n[TB_DA1] = n[TB_A1];
+    n[TB_SMALL] = B * 512 + B + 64 + (size_t)d.c1gx * d.c1gy * B * 288;
+    size_t slab = (size_t)d.wg3_blocks * 9 * 128 * 64;
+    const size_t s_w2 = (size_t)d.wg2_blocks * 9 * 64 * 32, s_g = (size_t)d.ksplits * 768 * 1024;
+    if (s_w2 > slab) slab = s_w2;
+    if (s_g > slab) slab = s_g;
+    n[TB_SLAB] = slab;
+}
+
+size_t tws_layout(const TDims& d, size_t* off) {
+    size_t n[TB_COUNT], pos = 0;
+    tws_sizes(d, n);
+    for (int i = 0; i < TB_COUNT; ++i) {
+        off[i] = pos;
+        pos += sir_align_up(n[i] * sizeof(float), 256);
+    }
+    return pos;
+}
+
+const int kBnC[3] = {32, 64, 128}, kBnO[3] = {0, 32, 96};
+
+#define KCHECK() SIR_HIP_TRY(hipGetLastError())
+
+struct TPtrs {
+    float *a1, *z2, *a2, *z3, *x0, *gi, *g0, *g1, *y0, *y0d, *y1, *ctx, *bn, *bnb, *wp2, *wp3, *wht, *wr4, *wp2t, *wp3t;
+    float *dy1, *dy0, *dgi, *dgh, *dx0, *dz3, *da2, *dz2, *da1, *small, *slab;
+    float2* stats;
+};
+
+TPtrs carve(void* ws, const size_t* off) {
+    char* b = (char*)ws;
+    TPtrs p;
+    p.a1 = (float*)(b + off[TB_A1]); p.z2 = (float*)(b + off[TB_Z2]); p.a2 = (float*)(b + off[TB_A2]);
+    p.z3 = (float*)(b + off[TB_Z3]); p.x0 = (float*)(b + off[TB_X0]); p.gi = (float*)(b + off[TB_GI]);
+    p.g0 = (float*)(b + off[TB_G0]); p.g1 = (float*)(b + off[TB_G1]); p.y0 = (float*)(b + off[TB_Y0]);
+    p.y0d = (float*)(b + off[TB_Y0D]); p.y1 = (float*)(b + off[TB_Y1]); p.ctx = (float*)(b + off[TB_CTX]);
+    p.bn = (float*)(b + off[TB_BN]); p.bnb = (float*)(b + off[TB_BNB]); p.stats = (float2*)(b + off[TB_STATS]);
+    p.wp2 = (float*)(b + off[TB_WP2]); p.wp3 = (float*)(b + off[TB_WP3]); p.wht = (float*)(b + off[TB_WHT]);
+    p.wr4 = (float*)(b + off[TB_WR4]); p.wp2t = (float*)(b + off[TB_WP2T]); p.wp3t = (float*)(b + off[TB_WP3T]);
+    p.dy1 = (float*)(b + off[TB_DY1]); p.dy0 = (float*)(b + off[TB_DY0]); p.dgi = (float*)(b + off[TB_DGI]);
+    p.dgh = (float*)(b + off[TB_DGH]); p.dx0 = (float*)(b + off[TB_DX0]); p.dz3 = (float*)(b + off[TB_DZ3]);
+    p.da2 = (float*)(b + off[TB_DA2]); p.dz2 = (float*)(b + off[TB_DZ2]); p.da1 = (float*)(b + off[TB_DA1]);
+    p.small = (float*)(b + off[TB_SMALL]); p.slab = (float*)(b + off[TB_SLAB]);
+    return p;
+}
+
+int check_common(const char* who, sir_handle* h, const sir_model_weights* w, int batch, int t, void* ws, size_t bytes,
+                 TDims* d, size_t* off) {
+    if (!h || !w || !ws) { sir_set_error("%s: NULL argument", who); return SIR_EINVAL; }
+    if (!make_tdims(batch, t, d)) { sir_set_error("%s: unsupported shape batch=%d t_frames=%d", who, batch, t); return SIR_EINVAL; }
+    if (h->cfg.n_mels != 64) { sir_set_error("%s: the model is wired for 64 mels", who); return SIR_EUNSUPPORTED; }
+    if (w->num_classes < 1 || w->num_classes > 64) { sir_set_error("%s: num_classes=%d", who, w->num_classes); return SIR_EINVAL; }
+    const size_t need = tws_layout(*d, off);
+    if (bytes < need) { sir_set_error("%s: workspace %zu < %zu", who, bytes, need); return SIR_ENOMEM; }
+    if (((uintptr_t)ws & 255) != 0) { sir_set_error("%s: workspace must be 256-byte aligned", who); return SIR_EINVAL; }
+    return SIR_OK;
+}
+
+inline int grid_for(size_t n, int per_block = 256, int cap = 8192) {
+    size_t g = (n + per_block - 1) / per_block;
+    return (int)(g > (size_t)cap ? cap : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+size_t sir_train_workspace_bytes_impl(int batch, int t_frames) {
+    TDims d;
+    if (!make_tdims(batch, t_frames, &d)) return 0;
+    size_t off[TB_COUNT];
+    return tws_layout(d, off);
+}
+
+extern "C" int sir_model_train_workspace_offsets(const sir_handle* h, int batch, int t_frames, size_t* offsets, int n) {
+    (void)h;
+    TDims d;
+    if (!make_tdims(batch, t_frames, &d) || !offsets) { sir_set_error("sir_model_train_workspace_offsets: bad shape"); return SIR_EINVAL; }
+    size_t off[TB_COUNT];
+    tws_layout(d, off);
+    for (int i = 0; i < n && i < TB_COUNT; ++i) offsets[i] = off[i];
+    return TB_COUNT;
+}
+
+extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, float* const bn_running_mean[3],
+                                   float* const bn_running_var[3], const float* feats, int batch, int t_frames,
+                                   float bn_momentum, float dropout_p, uint64_t dropout_seed, float* logits,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
+    TDims d;
+    size_t off[TB_COUNT];
+    int rc = check_common("sir_model_train_fwd", h, w, batch, t_frames, workspace, workspace_bytes, &d, off);
+    if (rc != SIR_OK) return rc;
+    if (!feats || !logits || !bn_running_mean || !bn_running_var) { sir_set_error("sir_model_train_fwd: NULL argument"); return SIR_EINVAL; }
+    if (dropout_p < 0.0f || dropout_p >= 1.0f) { sir_set_error("sir_model_train_fwd: dropout_p=%f", dropout_p); return SIR_EINVAL; }
+    hipStream_t st = (hipStream_t)stream_;
+    TPtrs p = carve(workspace, off);
+    const int B = d.B, S = d.S, T = d.T;
+    float *scale = p.bn, *shift = p.bn + 224, *smean = p.bn + 448, *sinv = p.bn + 672;
+
+    hipLaunchKernelGGL(prep_conv_w_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], p.wp2, 32, 64);
+    hipLaunchKernelGGL(prep_conv_w_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], p.wp3, 64, 128);
+    for (int i = 0; i < 4; ++i)
+        hipLaunchKernelGGL(prep_whh_kernel, dim3(768), dim3(256), 0, st, w->gru_w_hh[i], p.wht + (size_t)i * 768 * 256);
+    KCHECK();
+
+    // conv1 block: statistics pass (recompute), finalize, then the fused conv+BN+ReLU+pool pass
+    {
+        const dim3 g1(d.c1gx, d.c1gy, B);
+        hipLaunchKernelGGL(conv1_stats_kernel, g1, dim3(256), 0, st, feats, w->conv_w[0], p.stats, 64, T);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(32), dim3(256), 0, st, (const float2*)p.stats, d.c1gx * d.c1gy * B, 32,
+                           (double)B * 64 * T, w->bn_w[0], w->bn_b[0], bn_running_mean[0], bn_running_var[0], bn_momentum,
+                           scale, shift, smean, sinv);
+        hipLaunchKernelGGL(conv1_bn_relu_pool_kernel, dim3((d.wp1 + C1_PCOLS - 1) / C1_PCOLS, d.c1gy, B), dim3(256), 0, st,
+                           feats, w->conv_w[0], scale, shift, p.a1, 64, T, 32, d.wp1);
+    }
+    // conv2 block: raw conv + partial statistics on MFMA, finalize, BN+ReLU+pool
+    {
+        constexpr size_t lds = (size_t)(8 * 4 + 2) * (4 * 2 + 2) * 36 * 4;
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<32, 64, 4, 2, 2>), dim3(d.c2gx, 1, B), dim3(256), lds, st, p.a1, p.wp2,
+                           (const float*)nullptr, (const float*)nullptr, p.z2, 32, d.wp1, 16, d.wp2, p.stats);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, d.c2gx * B, 64,
+                           (double)B * 32 * d.wp1, w->bn_w[1], w->bn_b[1], bn_running_mean[1], bn_running_var[1], bn_momentum,
+                           scale + 32, shift + 32, smean + 32, sinv + 32);
+        hipLaunchKernelGGL(bn_relu_pool_kernel<false>, dim3(grid_for((size_t)B * 16 * d.wp2 * 16)), dim3(256), 0, st, p.z2,
+                           scale + 32, shift + 32, p.a2, B, 32, d.wp1, 64, 16, d.wp2);
+    }
+    {
+        constexpr size_t lds = (size_t)(8 * 2 + 2) * (4 * 4 + 2) * 36 * 4;
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<64, 128, 2, 4, 2>), dim3(d.c3gx, 1, B), dim3(256), lds, st, p.a2, p.wp3,
+                           (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, d.c3gx * B, 128,
+                           (double)B * 16 * d.wp2, w->bn_w[2], w->bn_b[2], bn_running_mean[2], bn_running_var[2], bn_momentum,
+                           scale + 96, shift + 96, smean + 96, sinv + 96);
+        hipLaunchKernelGGL(bn_relu_pool_kernel<true>, dim3(grid_for((size_t)B * 8 * d.wp3 * 32)), dim3(256), 0, st, p.z3,
+                           scale + 96, shift + 96, p.x0, B, 16, d.wp2, 128, 8, d.wp3);
+    }
+    KCHECK();
+
+    const int M = B * S;
+    const dim3 ggrid(768 / GB_N, (M + GB_M - 1) / GB_M, 2);
+    const dim3 rgrid((B + GRU_BW - 1) / GRU_BW, 2);
+    hipLaunchKernelGGL(gemm_nt_bias_kernel, ggrid, dim3(256), 0, st, p.x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
+                       w->gru_b_ih[0], w->gru_b_ih[1], p.gi, 1536, M, 768, 1024);
+    hipLaunchKernelGGL(gru_recurrence_kernel<true>, rgrid, dim3(1024), 0, st, p.gi, p.wht, w->gru_b_hh[0], w->gru_b_hh[1],
+                       p.y0, B, S, p.g0);
+    const float* y0in = p.y0;
+    if (dropout_p > 0.0f) {
+        hipLaunchKernelGGL(dropout_kernel, dim3(grid_for((size_t)M * 512)), dim3(256), 0, st, p.y0, p.y0d, (size_t)M * 512,
+                           dropout_p, (unsigned long long)dropout_seed);
+        y0in = p.y0d;
+    }
+    hipLaunchKernelGGL(gemm_nt_bias_kernel, ggrid, dim3(256), 0, st, y0in, 512, w->gru_w_ih[2], w->gru_w_ih[3], 512,
+                       w->gru_b_ih[2], w->gru_b_ih[3], p.gi, 1536, M, 768, 512);
+    hipLaunchKernelGGL(gru_recurrence_kernel<true>, rgrid, dim3(1024), 0, st, p.gi, p.wht + (size_t)2 * 768 * 256,
+                       w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1);
+    hipLaunchKernelGGL(attention_pool_kernel, dim3(B), dim3(256), 0, st, p.y1, w->attn_w, w->attn_b, p.ctx, S);
+    hipLaunchKernelGGL(gemm_nt_bias_kernel, dim3((w->num_classes + GB_N - 1) / GB_N, (B + GB_M - 1) / GB_M, 1), dim3(256), 0, st,
+                       p.ctx, 512, w->fc_w, w->fc_w, 512, w->fc_b, w->fc_b, logits, w->num_classes, B, w->num_classes, 512);
+    KCHECK();
+    return SIR_OK;
+}
+
+extern "C" int sir_ce_loss(sir_handle* h, const float* logits, const int64_t* labels, int batch, int num_classes,
+                           float* loss, float* dlogits, float grad_scale, void* stream_) {
+    if (!h || !logits || !labels || !loss) { sir_set_error("sir_ce_loss: NULL argument"); return SIR_EINVAL; }
+    if (batch < 1 || num_classes < 1) { sir_set_error("sir_ce_loss: bad shape"); return SIR_EINVAL; }
+    hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, logits, (const long long*)labels, batch,
+                       num_classes, loss, dlogits, grad_scale);
+    KCHECK();
+    return SIR_OK;
+}
+
+namespace {
+
+// split-K "TN" product  out[M][N] = sum_k A[k][m] * B[k][n]  (slabs + deterministic reduce)
+void launch_tn(hipStream_t st, const TDims& d, const float* A, int lda, const float* Bm, int ldb, float* out, float* slab,
+               int M, int N, int K, int seq, int shift) {
+    const dim3 grid((N + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M, d.ksplits);
+    const size_t stride = (size_t)M * N;
+    float* dst = d.ksplits > 1 ? slab : out;
+    hipLaunchKernelGGL((gemm_general_kernel<true, true>), grid, dim3(256), 0, st, A, lda, Bm, (const float*)nullptr, 0, ldb, dst,
+                       N, stride, M, N, K, d.kchunk, seq, shift);
+    if (d.ksplits > 1)
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(stride)), dim3(256), 0, st, (const float*)slab, stride, d.ksplits,
+                           stride, out);
+}
+
+}  // namespace
+
+extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, const float* feats, const float* dlogits,
+                                   int batch, int t_frames, float dropout_p, uint64_t dropout_seed,
+                                   const sir_model_grads* g, void* workspace, size_t workspace_bytes, void* stream_) {
+    TDims d;
+    size_t off[TB_COUNT];
+    int rc = check_common("sir_model_train_bwd", h, w, batch, t_frames, workspace, workspace_bytes, &d, off);
+    if (rc != SIR_OK) return rc;
+    if (!feats || !dlogits || !g) { sir_set_error("sir_model_train_bwd: NULL argument"); return SIR_EINVAL; }
+    hipStream_t st = (hipStream_t)stream_;
+    TPtrs p = carve(workspace, off);
+    const int B = d.B, S = d.S, T = d.T, C = w->num_classes, M = B * S;
+    float *scale = p.bn, *shift = p.bn + 224, *smean = p.bn + 448, *sinv = p.bn + 672;
+    float *mdy = p.bnb, *mdyx = p.bnb + 224;
+    float* daw_part = p.small;
+    float* dab_part = p.small + (size_t)B * 512;
+    float* c1part = p.small + (size_t)B * 512 + B + 64;
+    const float* y0in = dropout_p > 0.0f ? p.y0d : p.y0;
+    const dim3 rgrid((B + GRU_BW - 1) / GRU_BW, 2);
+
+    // ---- head: fc + attention pooling ----------------------------------------------------
+    hipLaunchKernelGGL(fc_wgrad_kernel, dim3(C), dim3(256), 0, st, dlogits, (const float*)p.ctx, g->fc_w, g->fc_b, B, C);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, st, dlogits, w->fc_w, (const float*)p.y1, w->attn_w, w->attn_b,
+                       p.dy1, daw_part, dab_part, S, C);
+    hipLaunchKernelGGL(colsum_kernel, dim3(8), dim3(256), 0, st, (const float*)daw_part, B, 512, 512, g->attn_w);
+    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, st, (const float*)dab_part, B, 1, 1, g->attn_b);
+    for (int i = 0; i < 4; ++i)
+        hipLaunchKernelGGL(prep_whh_bwd_kernel, dim3(768), dim3(256), 0, st, w->gru_w_hh[i], p.wr4 + (size_t)i * 768 * 256);
+    KCHECK();
+
+    // ---- GRU layers, top down ----------------------------------------------------------------
+    for (int layer = 1; layer >= 0; --layer) {
+        const float* dy = layer ? p.dy1 : p.dy0;
+        const float* gates = layer ? p.g1 : p.g0;
+        const float* yout = layer ? p.y1 : p.y0;
+        const float* xin = layer ? y0in : p.x0;
+        const int in_sz = layer ? 512 : 1024;
+        hipLaunchKernelGGL(gru_bwd_kernel, rgrid, dim3(1024), 0, st, dy, gates, yout, (const float*)(p.wr4 + (size_t)2 * layer * 768 * 256),
+                           p.dgi, p.dgh, B, S);
+        for (int dir = 0; dir < 2; ++dir) {
+            const int gi_idx = 2 * layer + dir;
+            hipLaunchKernelGGL(colsum_kernel, dim3(12), dim3(256), 0, st, (const float*)(p.dgi + dir * 768), M, 1536, 768, g->gru_b_ih[gi_idx]);
+            hipLaunchKernelGGL(colsum_kernel, dim3(12), dim3(256), 0, st, (const float*)(p.dgh + dir * 768), M, 1536, 768, g->gru_b_hh[gi_idx]);
+            launch_tn(st, d, p.dgi + dir * 768, 1536, xin, in_sz, g->gru_w_ih[gi_idx], p.slab, 768, in_sz, M, 0, 0);
+            launch_tn(st, d, p.dgh + dir * 768, 1536, yout + dir * 256, 512, g->gru_w_hh[gi_idx], p.slab, 768, 256, M, S,
+                      dir ? 1 : -1);
+        }
+        // gradient wrt the layer input: dgi [M][1536] x [W_ih; W_ih_reverse] [1536][in]
+        float* dxin = layer ? p.dy0 : p.dx0;
+        hipLaunchKernelGGL((gemm_general_kernel<false, true>), dim3((in_sz + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M, 1), dim3(256), 0, st,
+                           (const float*)p.dgi, 1536, w->gru_w_ih[2 * layer], w->gru_w_ih[2 * layer + 1], 768, in_sz, dxin, in_sz,
+                           (size_t)0, M, in_sz, 1536, 1536, 0, 0);
+        if (layer == 1 && dropout_p > 0.0f)
+            hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for((size_t)M * 512)), dim3(256), 0, st, p.dy0, (size_t)M * 512,
+                               dropout_p, (unsigned long long)dropout_seed);
+        KCHECK();
+    }
+
+    // ---- conv3 block -------------------------------------------------------------------------
+    {
+        const int ppb = 64;
+        const size_t npix = (size_t)B * 8 * d.wp3;
+        const int nblk = (int)((npix + ppb - 1) / ppb);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, st, (const float*)p.z3, (const float*)p.dx0,
+                           scale + 96, shift + 96, smean + 96, sinv + 96, p.stats, B, 16, d.wp2, 128, 8, d.wp3, ppb);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, nblk, 128,
+                           (double)B * 16 * d.wp2, g->bn_w[2], g->bn_b[2], mdy + 96, mdyx + 96);
+        hipLaunchKernelGGL(bn_bwd_dz_kernel<true>, dim3(grid_for((size_t)B * 16 * d.wp2 * 32)), dim3(256), 0, st, (const float*)p.z3,
+                           (const float*)p.dx0, scale + 96, shift + 96, smean + 96, sinv + 96, mdy + 96, mdyx + 96, p.dz3, B, 16,
+                           d.wp2, 128, 8, d.wp3);
+        const int Wk = (d.wp2 + 1) & ~1;
+        const size_t lds = ((size_t)Wk * 128 + 3 * (size_t)(Wk + 2) * 64) * 4;
+        static bool attr3 = false;
+        if (!attr3) {
+            SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_mfma_kernel<64, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr3 = true;
+        }
+        if (lds > 160 * 1024) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
+        hipLaunchKernelGGL((conv_wgrad_mfma_kernel<64, 128>), dim3(d.wg3_blocks), dim3(576), lds, st, (const float*)p.dz3,
+                           (const float*)p.a2, p.slab, 16, d.wp2, d.wg3_rb);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 128 * 64 + 255) / 256), dim3(256), 0, st, (const float*)p.slab,
+                           d.wg3_blocks, 64, 128, g->conv_w[2]);
+        hipLaunchKernelGGL(prep_conv_wT_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], p.wp3t, 64, 128);
+        constexpr size_t ldsd = (size_t)(8 * 2 + 2) * (4 * 4 + 2) * 36 * 4;
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<128, 64, 2, 4, 2>), dim3(d.c3gx, 1, B), dim3(256), ldsd, st, (const float*)p.dz3,
+                           (const float*)p.wp3t, (const float*)nullptr, (const float*)nullptr, p.da2, 16, d.wp2, 8, d.wp3,
+                           (float2*)nullptr);
+        KCHECK();
+    }
+    // ---- conv2 block -------------------------------------------------------------------------
+    {
+        const int ppb = 64;
+        const size_t npix = (size_t)B * 16 * d.wp2;
+        const int nblk = (int)((npix + ppb - 1) / ppb);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, st, (const float*)p.z2, (const float*)p.da2,
+                           scale + 32, shift + 32, smean + 32, sinv + 32, p.stats, B, 32, d.wp1, 64, 16, d.wp2, ppb);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, nblk, 64,
+                           (double)B * 32 * d.wp1, g->bn_w[1], g->bn_b[1], mdy + 32, mdyx + 32);
+        hipLaunchKernelGGL(bn_bwd_dz_kernel<false>, dim3(grid_for((size_t)B * 32 * d.wp1 * 16)), dim3(256), 0, st, (const float*)p.z2,
+                           (const float*)p.da2, scale + 32, shift + 32, smean + 32, sinv + 32, mdy + 32, mdyx + 32, p.dz2, B, 32,
+                           d.wp1, 64, 16, d.wp2);
+        const int Wk = (d.wp1 + 1) & ~1;
+        const size_t lds = ((size_t)Wk * 64 + 3 * (size_t)(Wk + 2) * 32) * 4;
+        static bool attr2 = false;
+        if (!attr2) {
+            SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_mfma_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr2 = true;
+        }
+        if (lds > 160 * 1024) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
+        hipLaunchKernelGGL((conv_wgrad_mfma_kernel<32, 64>), dim3(d.wg2_blocks), dim3(576), lds, st, (const float*)p.dz2,
+                           (const float*)p.a1, p.slab, 32, d.wp1, d.wg2_rb);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 32 + 255) / 256), dim3(256), 0, st, (const float*)p.slab,
+                           d.wg2_blocks, 32, 64, g->conv_w[1]);
+        hipLaunchKernelGGL(prep_conv_wT_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], p.wp2t, 32, 64);
+        constexpr size_t ldsd = (size_t)(8 * 4 + 2) * (4 * 2 + 2) * 36 * 4;
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<64, 32, 4, 2, 2>), dim3(d.c2gx, 1, B), dim3(256), ldsd, st, (const float*)p.dz2,
+                           (const float*)p.wp2t, (const float*)nullptr, (const float*)nullptr, p.da1, 32, d.wp1, 16, d.wp2,
+                           (float2*)nullptr);
+        KCHECK();
+    }
+    // ---- conv1 block (recomputed) ------------------------------------------------------------
+    {
+        const dim3 g1(d.c1gx, d.c1gy, B);
+        const int nblk = d.c1gx * d.c1gy * B;
+        hipLaunchKernelGGL(conv1_bwd_kernel<false>, g1, dim3(256), 0, st, feats, w->conv_w[0], (const float*)p.da1, scale, shift,
+                           smean, sinv, (const float*)nullptr, (const float*)nullptr, (float*)p.stats, 64, T, 32, d.wp1);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(32), dim3(256), 0, st, (const float2*)p.stats, nblk, 32, (double)B * 64 * T,
+                           g->bn_w[0], g->bn_b[0], mdy, mdyx);
+        hipLaunchKernelGGL(conv1_bwd_kernel<true>, g1, dim3(256), 0, st, feats, w->conv_w[0], (const float*)p.da1, scale, shift,
+                           smean, sinv, (const float*)mdy, (const float*)mdyx, c1part, 64, T, 32, d.wp1);
+        hipLaunchKernelGGL(colsum_kernel, dim3((288 + 63) / 64), dim3(256), 0, st, (const float*)c1part, nblk, 288, 288, g->conv_w[0]);
+        KCHECK();
+    }
+    return SIR_OK;
+}
+
+extern "C" int sir_adam_step(sir_handle* h, int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                             float* const* exp_avg_sq, const int64_t* sizes, int step, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, void* stream_) {
+    if (!h || !params || !grads || !exp_avg || !exp_avg_sq || !sizes) { sir_set_error("sir_adam_step: NULL argument"); return SIR_EINVAL; }
+    if (n_tensors < 1 || n_tensors > SIR_ADAM_MAX_TENSORS || step < 1) { sir_set_error("sir_adam_step: n_tensors=%d step=%d", n_tensors, step); return SIR_EINVAL; }
+    AdamTensors ts;
+    int blocks = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        ts.p[i] = params[i]; ts.g[i] = grads[i]; ts.m[i] = exp_avg[i]; ts.v[i] = exp_avg_sq[i]; ts.n[i] = sizes[i];
+        ts.first_block[i] = blocks;
+        blocks += (int)((sizes[i] + SIR_ADAM_CHUNK - 1) / SIR_ADAM_CHUNK);
+    }
+    ts.first_block[n_tensors] = blocks;
+    ts.count = n_tensors;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, ts, lr, beta1, beta2, eps, weight_decay,
+                       (float)bc1, (float)sqrt(bc2));
+    KCHECK();
+    return SIR_OK;
+}

@@ -70,6 +70,9 @@ struct SirProfScope {
 
 static inline size_t sir_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// model_train.hip
+size_t sir_train_workspace_bytes_impl(int batch, int t_frames);
+
 // features.hip
 int sir_features_launch(sir_handle* h, const void* wave, int wave_dtype, int64_t wave_stride,
                         const int32_t* lengths, int batch, int max_len, float* out, int t_pad,

@@ -9,7 +9,7 @@
 
 // conv1 is recomputed instead of stored (9 MACs per output): this pass only accumulates the
 // per-channel (sum, sum of squares) of the raw conv1 output over a 8 x 64 pixel tile.
-__global__ __launch_bounds__(256) void conv1_stats_kernel(const float* __restrict__ x, const float* __restrict__ w,
+static __global__ __launch_bounds__(256) void conv1_stats_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            float2* __restrict__ stats, int H, int W) {
     __shared__ float tile[C1_TR * C1_TC];
     __shared__ float red[8 * 32 * 2];
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void conv1_stats_kernel(const float* __restric
 // partial (sum, sumsq) [nblk][C] -> batch mean / biased var -> folded scale/shift for the forward,
 // saved mean / invstd for the backward, running statistics updated in place
 // (momentum 0.1, unbiased variance: torch.nn.BatchNorm2d training semantics).  One block per channel.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float2* __restrict__ stats, int nblk, int C, double count,
+static __global__ __launch_bounds__(256) void bn_finalize_kernel(const float2* __restrict__ stats, int nblk, int C, double count,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ run_mean, float* __restrict__ run_var,
                                                            float momentum, float* __restrict__ scale,
@@ -146,7 +146,7 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, size_t idx
     return (float)(unsigned)(x >> 40) * (1.0f / 16777216.0f) >= p;
 }
 
-__global__ void dropout_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, float p,
+static __global__ void dropout_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, float p,
                                unsigned long long seed) {
     const float sc = 1.0f / (1.0f - p);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -158,7 +158,7 @@ __global__ void dropout_kernel(const float* __restrict__ in, float* __restrict__
 // dlogits = (softmax - onehot) * grad_scale / B      (nn.CrossEntropyLoss(), train.py:242)
 // single workgroup, deterministic reduction
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+static __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
                                                        int B, int C, float* __restrict__ loss, float* __restrict__ dlogits,
                                                        float grad_scale) {
     __shared__ float red[256];
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
 //   dy_t = w_t dctx + ds_t a;  per-utterance partials of d attention.weight / d attention.bias
 // one workgroup per utterance
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ fcw,
+static __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ fcw,
                                                         const float* __restrict__ y, const float* __restrict__ aw,
                                                         const float* __restrict__ ab, float* __restrict__ dy,
                                                         float* __restrict__ daw_part, float* __restrict__ dab_part,
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 }
 
 // out[n] = sum_r in[r][n]   (deterministic column sums: bias / attention gradients)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int rows, int ld, int n_cols,
+static __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int rows, int ld, int n_cols,
                                                       float* __restrict__ out) {
     __shared__ float red[4][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
 }
 
 // dfc_w[j][c] = sum_b dlogits[b][j] ctx[b][c];  dfc_b[j] = sum_b dlogits[b][j]     (one block per class)
-__global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __restrict__ dlogits, const float* __restrict__ ctx,
+static __global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __restrict__ dlogits, const float* __restrict__ ctx,
                                                         float* __restrict__ dw, float* __restrict__ db, int B, int C) {
     const int j = blockIdx.x;
     for (int c = threadIdx.x; c < 512; c += 256) {
@@ -290,14 +290,14 @@ __global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __restrict__
 // Thread (u, b): gate math for hidden unit u of utterance b; thread (k, rs): partial of W_hh^T dgh
 // over gate rows [192 rs, 192 rs + 192).
 // ------------------------------------------------------------------------------------------
-__global__ void prep_whh_bwd_kernel(const float* __restrict__ w, float* __restrict__ wr4) {
+static __global__ void prep_whh_bwd_kernel(const float* __restrict__ w, float* __restrict__ wr4) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // over 768*256, layout [row/4][k][4]
     if (idx >= 768 * 256) return;
     const int e = idx & 3, k = (idx >> 2) & 255, r4 = idx >> 10;
     wr4[idx] = w[(size_t)(r4 * 4 + e) * 256 + k];
 }
 
-__global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ gates,
+static __global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ gates,
                                                         const float* __restrict__ y, const float* __restrict__ wr4,
                                                         float* __restrict__ dgi, float* __restrict__ dgh, int B, int S) {
     __shared__ __attribute__((aligned(16))) float gsh[GRU_BW * 768];       // dgh[b][row]
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void gemm_general_kernel(const float* __restri
 }
 
 // out[i] = sum_z slabs[z][i]
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, size_t slab_stride, int nslab, size_t n,
+static __global__ void slab_reduce_kernel(const float* __restrict__ slabs, size_t slab_stride, int nslab, size_t n,
                                    float* __restrict__ out) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float a = 0.0f;
@@ -512,7 +512,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, size_t slab_
 }
 
 // a[i] += b[i]  /  a[i] = a[i]*mask  helpers for the layer-0 dropout backward
-__global__ void dropout_bwd_kernel(float* __restrict__ g, size_t n, float p, unsigned long long seed) {
+static __global__ void dropout_bwd_kernel(float* __restrict__ g, size_t n, float p, unsigned long long seed) {
     const float sc = 1.0f / (1.0f - p);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         g[i] = dropout_keep(seed, i, p) ? g[i] * sc : 0.0f;
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 // sums the (sum dy, sum dy*xhat) partials -> dbeta, dgamma and the two per-channel means used by dz
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float2* __restrict__ part, int nblk, int C, double count,
+static __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float2* __restrict__ part, int nblk, int C, double count,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                float* __restrict__ mdy, float* __restrict__ mdyx) {
     __shared__ double rs[256], rq[256];
@@ -662,5 +662,244 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const float* __restrict_
         o.z = s.z * (dyv.z - m1.z - (zc.z - mu.z) * is.z * m2.z);
         o.w = s.w * (dyv.w - m1.w - (zc.w - mu.w) * is.w * m2.w);
         *reinterpret_cast<float4*>(dz + (((size_t)b * H + yy_) * W + x) * C + cc * 4) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv1 block backward (conv1 output is recomputed from the features, never stored).
+//   pass 1: partial (sum dy, sum dy*xhat) per channel      -> bn_bwd_finalize_kernel
+//   pass 2: dz = gamma*invstd*(dy - mean dy - xhat*mean(dy xhat)), dW1[c][tap] partials per block
+// Same tiling as conv1_bn_relu_pool_kernel: block = 4 x 32 pooled pixels, lane&31 = channel.
+// ------------------------------------------------------------------------------------------
+template <bool WGRAD>
+__global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ da, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, const float* __restrict__ mdy,
+                                                         const float* __restrict__ mdyx, float* __restrict__ part,
+                                                         int H, int W, int Hp, int Wp) {
+    constexpr int NV = WGRAD ? 9 : 2;
+    __shared__ float tile[C1_TR * C1_TC];
+    __shared__ float red[8 * 32 * NV];
+    const int b = blockIdx.z, py0 = blockIdx.y * C1_PROWS, px0 = blockIdx.x * C1_PCOLS;
+    const int tid = threadIdx.x, c = tid & 31, slot = tid >> 5;
+    const float* xb = x + (size_t)b * H * W;
+    for (int i = tid; i < C1_TR * C1_TC; i += 256) {
+        const int ty = i / C1_TC, tx = i - ty * C1_TC;
+        const int gy = 2 * py0 - 1 + ty, gx = 2 * px0 - 1 + tx;
+        tile[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xb[(size_t)gy * W + gx] : 0.0f;
+    }
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
+    const float s = scale[c], t = shift[c], mu = mean[c], is = invstd[c];
+    const float m1 = WGRAD ? mdy[c] : 0.0f, m2 = WGRAD ? mdyx[c] : 0.0f;
+    float accv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) accv[i] = 0.0f;
+    __syncthreads();
+    for (int i = 0; i < (C1_PROWS * C1_PCOLS) / 8; ++i) {
+        const int pp = slot + 8 * i, pyl = pp / C1_PCOLS, pxl = pp % C1_PCOLS;
+        const int py = py0 + pyl, px = px0 + pxl;
+        if (2 * py >= H || 2 * px >= W) continue;
+        float in[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) in[r][k] = tile[(2 * pyl + r) * C1_TC + 2 * pxl + k];
+        float a[4], yv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) v = fmaf(in[(q >> 1) + ky][(q & 1) + kx], wk[ky * 3 + kx], v);
+            a[q] = v;
+            yv[q] = fmaf(v, s, t);
+        }
+        const bool pooled = (py < Hp && px < Wp);
+        const float g = pooled ? da[(((size_t)b * Hp + py) * Wp + px) * 32 + c] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int gy = 2 * py + (q >> 1), gx = 2 * px + (q & 1);
+            if (gy >= H || gx >= W) continue;
+            const float dyq = pooled ? route1(yv[0], yv[1], yv[2], yv[3], q, g) : 0.0f;
+            const float xh = (a[q] - mu) * is;
+            if (!WGRAD) {
+                accv[0] += dyq;
+                accv[1] = fmaf(dyq, xh, accv[1]);
+            } else {
+                const float dzq = s * (dyq - m1 - xh * m2);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+                        accv[ky * 3 + kx] = fmaf(dzq, in[(q >> 1) + ky][(q & 1) + kx], accv[ky * 3 + kx]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[(slot * 32 + c) * NV + i] = accv[i];
+    __syncthreads();
+    const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    for (int o = tid; o < 32 * NV; o += 256) {
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += red[k * 32 * NV + o];
+        part[blk * 32 * NV + o] = v;           // !WGRAD: float2 (sum dy, sum dy xhat) per channel
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// data-gradient weights: the dgrad of a 3x3/pad-1 conv is the same conv with the roles of the
+// channel axes swapped and the taps flipped.  Output in the wp[g][co'][8] format of
+// prep_conv_w_kernel, where co' runs over the forward INPUT channels and the 8-group over the
+// forward OUTPUT channels.
+// ------------------------------------------------------------------------------------------
+static __global__ void prep_conv_wT_kernel(const float* __restrict__ w, float* __restrict__ wp, int cin_f, int cout_f) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = cin_f * 9 * cout_f;
+    if (idx >= total) return;
+    const int e = idx & 7, cop = (idx >> 3) % cin_f, g = (idx >> 3) / cin_f;
+    const int co_f = (g / 9) * 8 + e, tap = 8 - (g % 9);
+    wp[idx] = w[((size_t)co_f * cin_f + cop) * 9 + tap];
+}
+
+// ------------------------------------------------------------------------------------------
+// conv weight gradient on fp32 MFMA:  dW[co][ci][ky][kx] = sum_{b,y,x} dz[b][y][x][co] * a[b][y+ky-1][x+kx-1][ci]
+//   GEMM view: M = co, N = ci (per tap), K = pixels.  576 threads = 9 waves, wave = tap.
+//   One workgroup walks RB consecutive rows of one image: the dz row and a 3-row ring of the input
+//   (zero halo) sit in LDS; A operand = dz[pixel][co] and B operand = a[pixel+tap][ci] are both
+//   read with conflict-free ds_read_b32 (32 consecutive channels).  Per-workgroup partial
+//   gradients go to slab[blk][tap][co][ci] and are summed (and transposed to the torch layout) by
+//   wgrad_reduce_kernel: deterministic, no atomics.
+// ------------------------------------------------------------------------------------------
+template <int CIN, int COUT>
+__global__ __launch_bounds__(576) void conv_wgrad_mfma_kernel(const float* __restrict__ dz, const float* __restrict__ a,
+                                                               float* __restrict__ slab, int H, int W, int RB) {
+    constexpr int MT = COUT / 32, NT = CIN / 32;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int Wk = (W + 1) & ~1;                 // pixels per row rounded up to a k-pair
+    float* dzs = lds;                            // [Wk][COUT]
+    float* as_ = lds + (size_t)Wk * COUT;        // [3][Wk + 2][CIN]
+    const int arow = (Wk + 2) * CIN;
+    const int blocks_per_img = H / RB;
+    const int b = blockIdx.x / blocks_per_img, y0 = (blockIdx.x % blocks_per_img) * RB;
+    const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6;
+    const int ky = tap / 3, kx = tap % 3;
+    const int m = lane & 31, kh = lane >> 5;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    auto load_a_row = [&](int y) {               // input row y -> ring slot (y+1)%3, zero halo / out of range
+        float* dst = as_ + ((y + 1) % 3) * arow;
+        const bool valid = (y >= 0 && y < H);
+        const float* src = a + (((size_t)b * H + (valid ? y : 0)) * W) * CIN;
+        for (int i = tid; i < (Wk + 2) * (CIN / 4); i += 576) {
+            const int px = i / (CIN / 4), c4 = i % (CIN / 4);
+            const int gx = px - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid && gx >= 0 && gx < W) v = *reinterpret_cast<const float4*>(src + (size_t)gx * CIN + c4 * 4);
+            *reinterpret_cast<float4*>(dst + px * CIN + c4 * 4) = v;
+        }
+    };
+    load_a_row(y0 - 1);
+    load_a_row(y0);
+    for (int y = y0; y < y0 + RB; ++y) {
+        __syncthreads();                          // previous row fully consumed
+        load_a_row(y + 1);
+        const float* zsrc = dz + (((size_t)b * H + y) * W) * COUT;
+        for (int i = tid; i < Wk * (COUT / 4); i += 576) {
+            const int px = i / (COUT / 4), c4 = i % (COUT / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (px < W) v = *reinterpret_cast<const float4*>(zsrc + (size_t)px * COUT + c4 * 4);
+            *reinterpret_cast<float4*>(dzs + px * COUT + c4 * 4) = v;
+        }
+        __syncthreads();
+        const float* arow_p = as_ + ((y + ky) % 3) * arow;        // input row y + ky - 1 lives in slot (y+ky)%3
+        for (int s = 0; s < Wk / 2; ++s) {
+            const int px = 2 * s + kh;
+            float av[MT], bv[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = dzs[px * COUT + mt * 32 + m];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = arow_p[(px + kx) * CIN + nt * 32 + m];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    float* o = slab + ((size_t)blockIdx.x * 9 + tap) * COUT * CIN;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                o[(size_t)co * CIN + nt * 32 + m] = acc[mt][nt][r];
+            }
+}
+
+// dW[co][ci][tap] = sum_blk slab[blk][tap][co][ci]
+static __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk, int cin, int cout, float* __restrict__ dw) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // (tap, co, ci), ci fastest
+    const int total = 9 * cout * cin;
+    if (idx >= total) return;
+    const int ci = idx % cin, co = (idx / cin) % cout, tap = idx / (cin * cout);
+    float s = 0.0f;
+    for (int k = 0; k < nblk; ++k) s += slab[(size_t)k * total + idx];
+    dw[((size_t)co * cin + ci) * 9 + tap] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// multi-tensor Adam, coupled L2 weight decay (torch.optim.Adam, train.py:246-250): one launch
+// updates every parameter tensor.  Tensors are described by value in the kernel argument.
+// ------------------------------------------------------------------------------------------
+#define SIR_ADAM_MAX_TENSORS 32
+#define SIR_ADAM_CHUNK 4096
+
+struct AdamTensors {
+    float* p[SIR_ADAM_MAX_TENSORS];
+    const float* g[SIR_ADAM_MAX_TENSORS];
+    float* m[SIR_ADAM_MAX_TENSORS];
+    float* v[SIR_ADAM_MAX_TENSORS];
+    long long n[SIR_ADAM_MAX_TENSORS];
+    int first_block[SIR_ADAM_MAX_TENSORS + 1];
+    int count;
+};
+
+static __global__ __launch_bounds__(256) void adam_multi_kernel(AdamTensors ts, float lr, float beta1, float beta2, float eps,
+                                                          float weight_decay, float bc1, float bc2_sqrt) {
+    int ti = 0;
+    while (ti + 1 < ts.count && (int)blockIdx.x >= ts.first_block[ti + 1]) ++ti;
+    const long long base = (long long)((int)blockIdx.x - ts.first_block[ti]) * SIR_ADAM_CHUNK;
+    float* __restrict__ p = ts.p[ti];
+    const float* __restrict__ g = ts.g[ti];
+    float* __restrict__ m = ts.m[ti];
+    float* __restrict__ v = ts.v[ti];
+    const long long n = ts.n[ti];
+    const float step_size = lr / bc1;
+#pragma unroll 4
+    for (int k = 0; k < SIR_ADAM_CHUNK / 256; ++k) {
+        const long long i = base + threadIdx.x + 256 * k;
+        if (i >= n) break;
+        float gi = g[i];
+        const float pi = p[i];
+        if (weight_decay != 0.0f) gi = fmaf(weight_decay, pi, gi);
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - step_size * (mi / denom);
     }
 }

@@ -1,0 +1,144 @@
+"""Training-step glue: ``torch.autograd`` nodes around the HIP training kernels.
+
+``forward_train(model, x)`` returns logits whose backward runs ``sir_model_train_bwd`` and hands
+autograd the 29 parameter gradients as views of ONE flat fp32 buffer (3 261 184 elements); with
+``WORLD_SIZE > 1`` that buffer is averaged over ranks with a single RCCL all-reduce before the
+views are returned, so the update equals single-GPU training on the global batch.
+``fused_cross_entropy`` is the HIP form of the reference's ``nn.CrossEntropyLoss()`` (train.py:242).
+Only pointers move through Python; no arithmetic of the step is done by torch ops.
+"""
+import ctypes as C
+import itertools
+
+import torch
+
+from . import _native, ops
+from .dist_utils import (ShardSampler, all_reduce_mean_, all_reduce_sum_, broadcast_module_,  # noqa: F401
+                         init_distributed, shutdown_distributed, world_size)
+from .featurizer import get_featurizer
+
+_seed_counter = itertools.count(1)
+
+
+def param_list(mod):
+    """Parameters in ``named_parameters`` order (== the reference's state_dict order minus buffers)."""
+    return [p for _, p in mod.named_parameters()]
+
+
+class GradBuffer:
+    """One flat gradient buffer with per-parameter views + the matching ``sir_model_grads`` struct."""
+
+    def __init__(self, mod):
+        params = param_list(mod)
+        dev = params[0].device
+        self.flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for p in params:
+            self.views.append(self.flat[off: off + p.numel()].view_as(p))
+            off += p.numel()
+        by_name = {n: v for (n, _), v in zip(mod.named_parameters(), self.views)}
+        g = _native.ModelGrads()
+        for i in range(3):
+            g.conv_w[i] = by_name[f"conv{i + 1}.weight"].data_ptr()
+            g.bn_w[i] = by_name[f"bn{i + 1}.weight"].data_ptr()
+            g.bn_b[i] = by_name[f"bn{i + 1}.bias"].data_ptr()
+        for i, suf in enumerate(ops.GRU_SUFFIXES):
+            g.gru_w_ih[i] = by_name["gru.weight_ih" + suf].data_ptr()
+            g.gru_w_hh[i] = by_name["gru.weight_hh" + suf].data_ptr()
+            g.gru_b_ih[i] = by_name["gru.bias_ih" + suf].data_ptr()
+            g.gru_b_hh[i] = by_name["gru.bias_hh" + suf].data_ptr()
+        g.attn_w = by_name["attention.weight"].data_ptr()
+        g.attn_b = by_name["attention.bias"].data_ptr()
+        g.fc_w = by_name["fc.weight"].data_ptr()
+        g.fc_b = by_name["fc.bias"].data_ptr()
+        self.struct = g
+
+
+def _train_state(mod):
+    st = getattr(mod, "_sir_train", None)
+    if st is None or st["grads"].flat.device != next(mod.parameters()).device:
+        st = {"grads": GradBuffer(mod), "ws": ops.Workspace()}
+        mod._sir_train = st
+    return st
+
+
+def _bn_ptr_arrays(mod):
+    rm = (C.c_void_p * 3)(*[getattr(mod, f"bn{i}").running_mean.data_ptr() for i in (1, 2, 3)])
+    rv = (C.c_void_p * 3)(*[getattr(mod, f"bn{i}").running_var.data_ptr() for i in (1, 2, 3)])
+    return rm, rv
+
+
+class _TrainStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, dropout_p, *params):
+        lib = _native.lib()
+        h = get_featurizer().handle
+        bsz, _, t = x.shape
+        st = _train_state(mod)
+        need = lib.sir_model_workspace_bytes(h, bsz, t, 1)
+        if need == 0:
+            raise _native.SirError(f"unsupported shape batch={bsz} frames={t}")
+        ws = st["ws"].get(need, x.device)
+        w, keep = ops.cached_weights(mod)
+        rm, rv = _bn_ptr_arrays(mod)
+        logits = torch.empty((bsz, w.num_classes), dtype=torch.float32, device=x.device)
+        seed = next(_seed_counter) * 0x9E3779B97F4A7C15 % (1 << 64)
+        momentum = float(mod.bn1.momentum if mod.bn1.momentum is not None else 0.1)
+        rc = lib.sir_model_train_fwd(h, C.byref(w), rm, rv, x.data_ptr(), bsz, t, momentum, float(dropout_p), seed,
+                                     logits.data_ptr(), ws.data_ptr(), ws.numel(), _native.current_stream_ptr())
+        _native.check(rc, "sir_model_train_fwd")
+        for i in (1, 2, 3):
+            getattr(mod, f"bn{i}").num_batches_tracked.add_(1)
+        ctx.mod, ctx.x, ctx.seed, ctx.dropout_p, ctx.ws = mod, x, seed, float(dropout_p), ws
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        lib = _native.lib()
+        mod, x = ctx.mod, ctx.x
+        h = get_featurizer().handle
+        st = _train_state(mod)
+        w, keep = ops.cached_weights(mod)
+        dlogits = dlogits.contiguous()
+        bsz, _, t = x.shape
+        rc = lib.sir_model_train_bwd(h, C.byref(w), x.data_ptr(), dlogits.data_ptr(), bsz, t, ctx.dropout_p, ctx.seed,
+                                     C.byref(st["grads"].struct), ctx.ws.data_ptr(), ctx.ws.numel(),
+                                     _native.current_stream_ptr())
+        _native.check(rc, "sir_model_train_bwd")
+        all_reduce_mean_(st["grads"].flat)          # the one exchange step of data-parallel training
+        return (None, None, None) + tuple(st["grads"].views)
+
+
+def forward_train(mod, x):
+    """Training-mode forward of ``CNNAudioGRU`` (batch-statistics BN, inter-layer dropout
+    ``mod.gru.dropout``), differentiable wrt the module's parameters."""
+    _native.require_hip(x)
+    x = ops._as_features(x)
+    return _TrainStep.apply(x, mod, float(mod.gru.dropout), *param_list(mod))
+
+
+class _FusedCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        lib = _native.lib()
+        logits = logits.contiguous()
+        labels = labels.to(torch.int64).contiguous()
+        _native.require_hip(logits, labels)
+        bsz, ncls = logits.shape
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        dlogits = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
+        rc = lib.sir_ce_loss(get_featurizer().handle, logits.data_ptr(), labels.data_ptr(), bsz, ncls, loss.data_ptr(),
+                             dlogits.data_ptr() if dlogits is not None else None, 1.0, _native.current_stream_ptr())
+        _native.check(rc, "sir_ce_loss")
+        ctx.dlogits = dlogits
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        # loss.backward() passes 1.0; a general scalar is applied by the (tiny) multiply below
+        return ctx.dlogits * grad_out, None
+
+
+def fused_cross_entropy(logits, labels):
+    """``nn.CrossEntropyLoss()`` (mean over the batch) computed by ``sir_ce_loss``."""
+    return _FusedCE.apply(logits, labels)
