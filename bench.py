@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step leg")
+    ap.add_argument("--train-steps", type=int, default=20)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -223,6 +225,54 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # second leg (reported inside the same JSON line): the training step of BASELINE configs[2]/[3]
+    # -- fused HIP features + forward/backward + Adam at per-GPU batch 256; with N > 1 each step
+    # ends in one RCCL all-reduce (mean) of the flat 13 MB gradient buffer.
+    gpu_pred32 = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # predictions of the sample the CPU baseline runs, taken before the training leg moves the weights
+        _, gpu_pred32 = model.predict(fz(synth.synth_clips(32, CLIP_LEN, seed=1234).to(dev)))
+        gpu_pred32 = gpu_pred32.cpu()
+    train_info = None
+    if not args.no_train:
+        from sir_amd import train_ops
+        from sir_amd.optim import FusedAdam
+        model.train()
+        opt = FusedAdam(model.parameters(), lr=5e-5, weight_decay=1e-4)
+        labels = torch.randint(0, NUM_CLASSES, (BATCH,), device=dev)
+
+        def tstep(i):
+            fz(pool[i % N_POOL], lengths, t_pad=T_PAD, out=feats)
+            opt.zero_grad(set_to_none=True)
+            loss = train_ops.fused_cross_entropy(model(feats), labels)
+            loss.backward()
+            opt.step()
+
+        for i in range(5):
+            tstep(i)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.train_steps):
+            tstep(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t_el = time.perf_counter() - t1
+        if dist is not None:
+            tm = torch.tensor([t_el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            t_el = float(tm.item())
+        train_info = {"value": round(BATCH * world * args.train_steps / t_el, 1), "unit": "utterances/s",
+                      "ms_per_step": round(t_el / args.train_steps * 1e3, 4), "steps": args.train_steps,
+                      "workload": "waveform batch 256/GPU -> HIP features -> forward/backward (dropout 0.5, batch-stat BN) "
+                                  "-> Adam(lr 5e-5, wd 1e-4)" + (", RCCL all-reduce of 13 MB grads" if world > 1 else ""),
+                      "model_flops_per_utt_fwd_bwd": 3 * sum(FLOPS_PER_UTT.values())}
+        model.eval()
+        if rank == 0:
+            log(f"train leg: {train_info['value']} utt/s")
+
     if rank == 0:
         total_utts = BATCH * world * args.steps
         value = total_utts / elapsed
@@ -255,14 +305,14 @@ def main():
                                "achieved_GBs": round(FEATURE_BYTES_PER_UTT * BATCH / (feat_ms * 1e-3) / 1e9, 1) if feat_ms else None,
                                "peak_GBs": PEAK_HBM_GBS},
         }
+        if train_info is not None:
+            out["train"] = train_info
         if world == 1 and not args.no_cpu_baseline:
             base, cpu_pred = cpu_baseline()
             out["cpu_baseline"] = base
             out["speedup_vs_cpu_all_cores"] = round(value / base["value"], 1)
             # parity flag on the very sample the CPU baseline ran: predicted indices identical
-            clips = synth.synth_clips(32, CLIP_LEN, seed=1234).to(dev)
-            _, gpu_pred = model.predict(fz(clips))
-            out["parity"] = {"argmax_identical_on_cpu_sample": bool(torch.equal(gpu_pred.cpu(), cpu_pred))}
+            out["parity"] = {"argmax_identical_on_cpu_sample": bool(torch.equal(gpu_pred32, cpu_pred))}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

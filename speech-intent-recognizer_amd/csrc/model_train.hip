@@ -283,6 +283,8 @@ extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, co
     float* daw_part = p.small;
     float* dab_part = p.small + (size_t)B * 512;
     float* c1part = p.small + (size_t)B * 512 + B + 64;
+    float* bsum_i = p.slab;                              // [B][1536] x2, consumed before the slabs are used
+    float* bsum_h = p.slab + (size_t)B * 1536;
     const float* y0in = dropout_p > 0.0f ? p.y0d : p.y0;
     const dim3 rgrid((B + GRU_BW - 1) / GRU_BW, 2);
 
@@ -304,11 +306,14 @@ extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, co
         const float* xin = layer ? y0in : p.x0;
         const int in_sz = layer ? 512 : 1024;
         hipLaunchKernelGGL(gru_bwd_kernel, rgrid, dim3(1024), 0, st, dy, gates, yout, (const float*)(p.wr4 + (size_t)2 * layer * 768 * 256),
-                           p.dgi, p.dgh, B, S);
+                           p.dgi, p.dgh, bsum_i, bsum_h, B, S);
+        for (int dir = 0; dir < 2; ++dir) {      // bias gradients first: bsum_* alias the slab area used below
+            const int gi_idx = 2 * layer + dir;
+            hipLaunchKernelGGL(colsum_kernel, dim3(12), dim3(256), 0, st, (const float*)(bsum_i + dir * 768), B, 1536, 768, g->gru_b_ih[gi_idx]);
+            hipLaunchKernelGGL(colsum_kernel, dim3(12), dim3(256), 0, st, (const float*)(bsum_h + dir * 768), B, 1536, 768, g->gru_b_hh[gi_idx]);
+        }
         for (int dir = 0; dir < 2; ++dir) {
             const int gi_idx = 2 * layer + dir;
-            hipLaunchKernelGGL(colsum_kernel, dim3(12), dim3(256), 0, st, (const float*)(p.dgi + dir * 768), M, 1536, 768, g->gru_b_ih[gi_idx]);
-            hipLaunchKernelGGL(colsum_kernel, dim3(12), dim3(256), 0, st, (const float*)(p.dgh + dir * 768), M, 1536, 768, g->gru_b_hh[gi_idx]);
             launch_tn(st, d, p.dgi + dir * 768, 1536, xin, in_sz, g->gru_w_ih[gi_idx], p.slab, 768, in_sz, M, 0, 0);
             launch_tn(st, d, p.dgh + dir * 768, 1536, yout + dir * 256, 512, g->gru_w_hh[gi_idx], p.slab, 768, 256, M, S,
                       dir ? 1 : -1);
@@ -396,7 +401,10 @@ extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, co
                            g->bn_w[0], g->bn_b[0], mdy, mdyx);
         hipLaunchKernelGGL(conv1_bwd_kernel<true>, g1, dim3(256), 0, st, feats, w->conv_w[0], (const float*)p.da1, scale, shift,
                            smean, sinv, (const float*)mdy, (const float*)mdyx, c1part, 64, T, 32, d.wp1);
-        hipLaunchKernelGGL(colsum_kernel, dim3((288 + 63) / 64), dim3(256), 0, st, (const float*)c1part, nblk, 288, 288, g->conv_w[0]);
+        float* c1tmp = (float*)p.stats;               // [128][288], the BN partials are consumed by now
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((288 + 63) / 64, 128), dim3(256), 0, st, (const float*)c1part, nblk, 288,
+                           288, c1tmp);
+        hipLaunchKernelGGL(colsum_kernel, dim3((288 + 63) / 64), dim3(256), 0, st, (const float*)c1tmp, 128, 288, 288, g->conv_w[0]);
         KCHECK();
     }
     return SIR_OK;

@@ -265,6 +265,22 @@ static __global__ __launch_bounds__(256) void colsum_kernel(const float* __restr
     if (part == 0 && col < n_cols) out[col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// first stage for tall inputs: out[chunk][n] = sum over the rows of chunk `blockIdx.y` (then colsum_kernel)
+static __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ in, int rows, int ld, int n_cols,
+                                                                     float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int per = (rows + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    float a = 0.0f;
+    if (col < n_cols)
+        for (int r = r0 + part; r < r1; r += 4) a += in[(size_t)r * ld + col];
+    red[part][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (part == 0 && col < n_cols)
+        out[(size_t)blockIdx.y * n_cols + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 // dfc_w[j][c] = sum_b dlogits[b][j] ctx[b][c];  dfc_b[j] = sum_b dlogits[b][j]     (one block per class)
 static __global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __restrict__ dlogits, const float* __restrict__ ctx,
                                                         float* __restrict__ dw, float* __restrict__ db, int B, int C) {
@@ -299,7 +315,11 @@ static __global__ void prep_whh_bwd_kernel(const float* __restrict__ w, float* _
 
 static __global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ gates,
                                                         const float* __restrict__ y, const float* __restrict__ wr4,
-                                                        float* __restrict__ dgi, float* __restrict__ dgh, int B, int S) {
+                                                        float* __restrict__ dgi, float* __restrict__ dgh,
+                                                        float* __restrict__ bsum_i, float* __restrict__ bsum_h, int B,
+                                                        int S) {
+    // bsum_i / bsum_h [B][1536]: per-utterance sums over time of dgi / dgh (bias gradients are their
+    // column sums over B rows instead of B*S rows)
     __shared__ __attribute__((aligned(16))) float gsh[GRU_BW * 768];       // dgh[b][row]
     __shared__ float ps[4 * GRU_BW * GRU_H];                               // partial[rs][b][k]
     const int dir = blockIdx.y, b0 = blockIdx.x * GRU_BW;
@@ -308,6 +328,7 @@ static __global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __res
     const bool bvalid = (b0 + bme) < B;
     const float4* w4 = reinterpret_cast<const float4*>(wr4) + (size_t)dir * 192 * 256;
     float dh_carry = 0.0f;
+    float sum_r = 0.f, sum_z = 0.f, sum_n = 0.f, sum_nr = 0.f;
     for (int step = S - 1; step >= 0; --step) {
         const int t = dir ? (S - 1 - step) : step;                // time index processed at `step`
         const int tp = dir ? t + 1 : t - 1;                       // where h_prev lives (invalid at step 0)
@@ -329,6 +350,7 @@ static __global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __res
             float* gh_o = dgh + row * 1536 + dir * 768;
             gi_o[u] = drp; gi_o[256 + u] = dzp; gi_o[512 + u] = dnp;
             gh_o[u] = drp; gh_o[256 + u] = dzp; gh_o[512 + u] = dnr;
+            sum_r += drp; sum_z += dzp; sum_n += dnp; sum_nr += dnr;
         }
         gsh[bme * 768 + u] = drp; gsh[bme * 768 + 256 + u] = dzp; gsh[bme * 768 + 512 + u] = dnr;
         __syncthreads();
@@ -351,6 +373,12 @@ static __global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __res
         dh_carry = dhz + ps[(0 * GRU_BW + bme) * GRU_H + u] + ps[(1 * GRU_BW + bme) * GRU_H + u] +
                    ps[(2 * GRU_BW + bme) * GRU_H + u] + ps[(3 * GRU_BW + bme) * GRU_H + u];
         __syncthreads();
+    }
+    if (bvalid) {
+        float* bi = bsum_i + (size_t)(b0 + bme) * 1536 + dir * 768;
+        float* bh = bsum_h + (size_t)(b0 + bme) * 1536 + dir * 768;
+        bi[u] = sum_r; bi[256 + u] = sum_z; bi[512 + u] = sum_n;
+        bh[u] = sum_r; bh[256 + u] = sum_z; bh[512 + u] = sum_nr;
     }
 }
 
