@@ -124,7 +124,7 @@ extern "C" int sir_features_fwd(sir_handle* h, const void* wave, int wave_dtype,
 static const char* const kKernelNames[SIR_K_COUNT] = {
     "feat_frames", "feat_normalise", "weight_prep", "conv1_bn_relu_pool", "conv2_mfma_bn_relu_pool",
     "conv3_mfma_bn_relu_pool", "gemm_ih_l0", "gru_recurrence_l0", "gemm_ih_l1", "gru_recurrence_l1",
-    "attention_pool", "fc_head"};
+    "attention_pool_fc_argmax", "unused"};
 
 extern "C" int sir_profile_kernel_count(void) { return SIR_K_COUNT; }
 extern "C" const char* sir_profile_kernel_name(int id) { return (id >= 0 && id < SIR_K_COUNT) ? kKernelNames[id] : ""; }

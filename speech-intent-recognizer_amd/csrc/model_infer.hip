@@ -129,13 +129,13 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     {
         SirProfScope prof(h, SIR_K_CONV2, st);
         constexpr size_t lds = (size_t)(8 * 4 + 2) * (4 * 2 + 2) * 36 * 4;
-        hipLaunchKernelGGL((conv3x3_mfma_kernel<32, 64, 4, 2, 0>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), lds, st, a1, wp2,
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<32, 64, 4, 2, 0, 2>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), lds, st, a1, wp2,
                            bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
     }
     {
         SirProfScope prof(h, SIR_K_CONV3, st);
-        constexpr size_t lds = (size_t)(8 * 2 + 2) * (4 * 4 + 2) * 36 * 4;
-        hipLaunchKernelGGL((conv3x3_mfma_kernel<64, 128, 2, 4, 1>), dim3((d.wp2 + 15) / 16, 1, B), dim3(256), lds, st, a2, wp3,
+        constexpr size_t lds = (size_t)(8 * 2 + 2) * (4 * 2 + 2) * 36 * 4;
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<64, 128, 2, 2, 1, 1>), dim3((d.wp2 + 7) / 8, 1, B), dim3(256), lds, st, a2, wp3,
                            bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)nullptr);
     }
     SIR_KCHECK();
@@ -144,29 +144,29 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     const int M = B * S;
     const dim3 ggrid(768 / GB_N, (M + GB_M - 1) / GB_M, 2);
     const dim3 rgrid((B + GRU_BW - 1) / GRU_BW, 2);
+    static bool gru_attr = false;
+    if (!gru_attr) {
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_recurrence_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU_LDS_BYTES));
+        gru_attr = true;
+    }
     { SirProfScope prof(h, SIR_K_GEMM_IH0, st);
-    hipLaunchKernelGGL(gemm_nt_bias_kernel, ggrid, dim3(256), 0, st, x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
+    hipLaunchKernelGGL(gemm_nt_bias_kernel<32>, ggrid, dim3(256), 0, st, x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
                        w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024); }
     { SirProfScope prof(h, SIR_K_GRU0, st);
-    hipLaunchKernelGGL(gru_recurrence_kernel<false>, rgrid, dim3(1024), 0, st, gi, wht, w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S,
+    hipLaunchKernelGGL(gru_recurrence_kernel<false>, rgrid, dim3(GRU_THREADS), GRU_LDS_BYTES, st, gi, wht, w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S,
                        (float*)nullptr); }
     { SirProfScope prof(h, SIR_K_GEMM_IH1, st);
-    hipLaunchKernelGGL(gemm_nt_bias_kernel, ggrid, dim3(256), 0, st, y0, 512, w->gru_w_ih[2], w->gru_w_ih[3], 512,
+    hipLaunchKernelGGL(gemm_nt_bias_kernel<32>, ggrid, dim3(256), 0, st, y0, 512, w->gru_w_ih[2], w->gru_w_ih[3], 512,
                        w->gru_b_ih[2], w->gru_b_ih[3], gi, 1536, M, 768, 512); }
     { SirProfScope prof(h, SIR_K_GRU1, st);
-    hipLaunchKernelGGL(gru_recurrence_kernel<false>, rgrid, dim3(1024), 0, st, gi, wht + (size_t)2 * 768 * 256, w->gru_b_hh[2],
+    hipLaunchKernelGGL(gru_recurrence_kernel<false>, rgrid, dim3(GRU_THREADS), GRU_LDS_BYTES, st, gi, wht + (size_t)2 * 768 * 256, w->gru_b_hh[2],
                        w->gru_b_hh[3], y1, B, S, (float*)nullptr); }
     SIR_KCHECK();
 
     // ---- attention pooling + classifier head ------------------------------------------------
     { SirProfScope prof(h, SIR_K_ATTN, st);
-    hipLaunchKernelGGL(attention_pool_kernel, dim3(B), dim3(256), 0, st, y1, w->attn_w, w->attn_b, ctx, S); }
-    SirProfScope prof_fc(h, SIR_K_FC, st);
-    hipLaunchKernelGGL(gemm_nt_bias_kernel, dim3((w->num_classes + GB_N - 1) / GB_N, (B + GB_M - 1) / GB_M, 1), dim3(256), 0, st,
-                       ctx, 512, w->fc_w, w->fc_w, 512, w->fc_b, w->fc_b, logits, w->num_classes, B, w->num_classes, 512);
-    if (argmax)
-        hipLaunchKernelGGL(argmax_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, st, logits, (long long*)argmax, B,
-                           w->num_classes);
+    hipLaunchKernelGGL(attention_pool_kernel, dim3(B), dim3(256), 0, st, y1, w->attn_w, w->attn_b, ctx, S, w->fc_w, w->fc_b,
+                       w->num_classes, logits, (long long*)argmax); }
     SIR_KCHECK();
     return SIR_OK;
 }

@@ -109,14 +109,14 @@ static __global__ __launch_bounds__(256) void conv1_bn_relu_pool_kernel(
 // OUT_MODE 0: NHWC [B][Hp][Wp][COUT];  1: GRU input [B][Wp][COUT*Hp] with feature = co*Hp + py
 //   (the permute(0,3,1,2).view of models/models.py:55-57, folded into the store).
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int PR, int PC, int OUT_MODE>
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
+template <int CIN, int COUT, int PR, int PC, int OUT_MODE, int MT = 2>
+__global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void conv3x3_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp,
     float2* __restrict__ stats = nullptr) {
-    constexpr int NT = COUT / 32, MT = 2, CK = 32, PS = CK + 4;
+    constexpr int NT = COUT / 32, CK = 32, PS = CK + 4;     // MT patches per wave, NT channel tiles
     constexpr int TR = 8 * PR, TC = 4 * PC, TROWS = TR + 2, TCOLS = TC + 2;
-    static_assert(PR * PC == 8 && CIN % CK == 0, "tile shape");
+    static_assert(PR * PC == 4 * MT && CIN % CK == 0 && (MT == 1 || PR % 2 == 0), "tile shape");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.z, ty0 = blockIdx.y * TR, tx0 = blockIdx.x * TC;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -126,11 +126,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     int aoff[MT], pr_[MT], pc_[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int pi = 2 * wv + mt;
-        pr_[mt] = pi / PC;
-        pc_[mt] = pi % PC;
+        const int pi = MT * wv + mt;             // column-major patch order: a wave's two patches share a
+        pr_[mt] = pi % PR;                       // patch column, so a partially covered last tile leaves
+        pc_[mt] = pi / PR;                       // whole waves idle instead of half-used waves
         aoff[mt] = ((8 * pr_[mt] + pyl) * TCOLS + 4 * pc_[mt] + pxl) * PS + kh * 4;
     }
+    // a wave whose patch column starts at or beyond W contributes nothing: it skips its MFMA loop
+    // (wave-uniform, made provably so with readfirstlane so the branch is scalar)
+    bool pvalid[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) pvalid[mt] = __builtin_amdgcn_readfirstlane((tx0 + 4 * pc_[mt] < W) ? 1 : 0) != 0;
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -154,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             *reinterpret_cast<float4*>(lds + pix * PS + part * 4) = v;
         }
         __syncthreads();
+        if (!pvalid[0]) continue;                 // wave-uniform: this wave's patches lie beyond W
         float4 bcur[NT], bnxt[NT];
         const int g0 = cc * 36;
 #pragma unroll
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             for (int mt = 0; mt < MT; ++mt)
                 a[mt] = *reinterpret_cast<const float4*>(lds + aoff[mt] + (ky * TCOLS + kx) * PS + cgl * 8);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bcur[nt].x, acc[mt][nt], 0, 0, 0);
@@ -178,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bcur[nt].z, acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bcur[nt].w, acc[mt][nt], 0, 0, 0);
                 }
+            }
             if (it + 1 < 36) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bcur[nt] = bnxt[nt];
@@ -277,46 +284,51 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 //   floats so the ds_read_b128 operand reads are bank-conflict-free; global->register prefetch of
 //   the next k-tile overlaps the MFMAs of the current one.
 // ------------------------------------------------------------------------------------------
-constexpr int GB_M = 128, GB_N = 64, GB_K = 32, GB_S = GB_K + 4;
-
-static __global__ __launch_bounds__(256) void gemm_nt_bias_kernel(
+constexpr int GB_M = 128, GB_N = 64, GB_K = 32, GB_S = GB_K + 4;     // general (backward) GEMM tile
+// forward NT GEMM, templated on the K-tile depth GF_K (32 measured faster than 64: more workgroups
+// per CU beat fewer barriers)
+template <int GF_K>
+__global__ __launch_bounds__(256) void gemm_nt_bias_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ B0, const float* __restrict__ B1, int ldb,
     const float* __restrict__ bias0, const float* __restrict__ bias1, float* __restrict__ C, int ldc,
     int M, int N, int K) {
-    __shared__ __attribute__((aligned(16))) float As[GB_M * GB_S];
-    __shared__ __attribute__((aligned(16))) float Bs[GB_N * GB_S];
+    constexpr int GF_S = GF_K + 4;
+    __shared__ __attribute__((aligned(16))) float As[GB_M * GF_S];
+    __shared__ __attribute__((aligned(16))) float Bs[GB_N * GF_S];
     const int z = blockIdx.z;
     const float* __restrict__ B = z ? B1 : B0;
     const float* __restrict__ bias = z ? bias1 : bias0;
     const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv >> 1, wn = wv & 1, m = lane & 31, kh = lane >> 5;
+    constexpr int C4 = GF_K / 4;                      // float4 per tile row
+    constexpr int NA = GB_M * C4 / 256, NB = GB_N * C4 / 256;
 
-    float4 ra[4], rb[2];
+    float4 ra[NA], rb[NB];
     auto load_tile = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 3, c4 = idx & 7;
-            ra[i] = (m0 + row < M) ? *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * lda + kt * GB_K + c4 * 4)
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + 256 * i, row = idx / C4, c4 = idx % C4;
+            ra[i] = (m0 + row < M) ? *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * lda + kt * GF_K + c4 * 4)
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 3, c4 = idx & 7;
-            rb[i] = (n0 + row < N) ? *reinterpret_cast<const float4*>(B + (size_t)(n0 + row) * ldb + kt * GB_K + c4 * 4)
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + 256 * i, row = idx / C4, c4 = idx % C4;
+            rb[i] = (n0 + row < N) ? *reinterpret_cast<const float4*>(B + (size_t)(n0 + row) * ldb + kt * GF_K + c4 * 4)
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 3, c4 = idx & 7;
-            *reinterpret_cast<float4*>(As + row * GB_S + c4 * 4) = ra[i];
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + 256 * i, row = idx / C4, c4 = idx % C4;
+            *reinterpret_cast<float4*>(As + row * GF_S + c4 * 4) = ra[i];
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 3, c4 = idx & 7;
-            *reinterpret_cast<float4*>(Bs + row * GB_S + c4 * 4) = rb[i];
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + 256 * i, row = idx / C4, c4 = idx % C4;
+            *reinterpret_cast<float4*>(Bs + row * GF_S + c4 * 4) = rb[i];
         }
     };
 
@@ -326,17 +338,17 @@ static __global__ __launch_bounds__(256) void gemm_nt_bias_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
 
-    const int nk = K / GB_K;
+    const int nk = K / GF_K;
     load_tile(0);
     store_tile();
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const float4 a0 = *reinterpret_cast<const float4*>(As + (wm * 64 + m) * GB_S + kk * 8 + kh * 4);
-            const float4 a1 = *reinterpret_cast<const float4*>(As + (wm * 64 + 32 + m) * GB_S + kk * 8 + kh * 4);
-            const float4 bq = *reinterpret_cast<const float4*>(Bs + (wn * 32 + m) * GB_S + kk * 8 + kh * 4);
+        for (int kk = 0; kk < GF_K / 8; ++kk) {
+            const float4 a0 = *reinterpret_cast<const float4*>(As + (wm * 64 + m) * GF_S + kk * 8 + kh * 4);
+            const float4 a1 = *reinterpret_cast<const float4*>(As + (wm * 64 + 32 + m) * GF_S + kk * 8 + kh * 4);
+            const float4 bq = *reinterpret_cast<const float4*>(Bs + (wn * 32 + m) * GF_S + kk * 8 + kh * 4);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bq.x, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bq.x, acc[1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bq.y, acc[0], 0, 0, 0);
@@ -370,86 +382,146 @@ static __global__ __launch_bounds__(256) void gemm_nt_bias_kernel(
 //   gi  [B*S][1536]   = x W_ih^T + b_ih for both directions (from the GEMM above)
 //   wt  [2][64][768][4] transposed W_hh (prep_whh_kernel), bhh [2][768]
 //   y   [B][S][512]   direction d writes columns d*256 .. d*256+255
-// One workgroup = 4 utterances of one direction for all S steps: no inter-workgroup traffic.
-// 1024 threads = 256 hidden units x 4 K-slices; each thread accumulates 3 gates x 4 utterances
-// over its 64-wide K slice (W_hh streamed from L2 as 16-byte coalesced loads, h broadcast from
-// LDS), slices are summed through LDS, then thread (u, b) applies the gate math.
+// One workgroup = GRU_BW utterances of one direction for all S steps: no inter-workgroup traffic.
+// 512 threads = 256 hidden units x 2 K-halves; a thread owns the 3 gate rows of its unit over
+// its 128-wide K half.  W_hh is 786 KB per direction -- more than a CU can hold -- and
+// re-streaming all of it from L2 every step is bound by the per-CU load path (round-1 profile:
+// 7.5 us/step).  So 34 % of each thread's weights stay in REGISTERS and 12.5 % in LDS for all S
+// steps (loaded once), and only the remaining 53 % is streamed per step as coalesced 16-byte
+// loads, which the FMA work of the step now covers.  h is broadcast from LDS; the two K-halves are
+// summed through LDS, then thread (u, b) applies the gate math for two utterances.
+// SAVE: also store (r, z, n, W_hn h + b_hn) per step for back-propagation through time,
+//   gates [B][S][2 dirs][4][256]
 // ------------------------------------------------------------------------------------------
-constexpr int GRU_H = 256, GRU_BW = 4;
+constexpr int GRU_H = 256, GRU_BW = 2;              // utterances per workgroup: 2 -> B/2 x 2 = 256 workgroups at B=256
+constexpr int GRU_NPART = 4;                        // K split: threads = 256 units x NPART
+constexpr int GRU_KPER4 = 64 / GRU_NPART;           // k/4 groups per part
+constexpr int GRU_KREG4 = 3;                        // k/4 groups per part held in registers
+constexpr int GRU_KLDS4 = 2;                        // ... held in LDS
+constexpr int GRU_KSTR4 = GRU_KPER4 - GRU_KREG4 - GRU_KLDS4;   // ... streamed from L2 each step
+constexpr int GRU_NQ = (GRU_BW + GRU_NPART - 1) / GRU_NPART;   // utterances finished per thread (bl = part + NPART*q)
+constexpr int GRU_THREADS = 256 * GRU_NPART;
+constexpr size_t GRU_LDS_BYTES =
+    (size_t)(GRU_NPART * GRU_KLDS4 * 3 * 256 * 4 + GRU_BW * GRU_H + GRU_NPART * GRU_BW * 3 * GRU_H) * 4;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// SAVE: also store (r, z, n, W_hn h + b_hn) per step for back-propagation through time,
-//   gates [B][S][2 dirs][4][256]
+__device__ __forceinline__ void gru_fma4(float (&acc)[GRU_BW], const float4 w, const float4 (&h4)[GRU_BW]) {
+#pragma unroll
+    for (int bb = 0; bb < GRU_BW; ++bb) {
+        acc[bb] = fmaf(w.x, h4[bb].x, acc[bb]); acc[bb] = fmaf(w.y, h4[bb].y, acc[bb]);
+        acc[bb] = fmaf(w.z, h4[bb].z, acc[bb]); acc[bb] = fmaf(w.w, h4[bb].w, acc[bb]);
+    }
+}
+
 template <bool SAVE>
-__global__ __launch_bounds__(1024) void gru_recurrence_kernel(
+__global__ __launch_bounds__(GRU_THREADS) void gru_recurrence_kernel(
     const float* __restrict__ gi, const float* __restrict__ wt, const float* __restrict__ bhh0,
-    const float* __restrict__ bhh1, float* __restrict__ y, int B, int S, float* __restrict__ gates = nullptr) {
-    __shared__ __attribute__((aligned(16))) float hs[GRU_BW * GRU_H];            // h[b][k]
-    __shared__ float ps[4 * GRU_BW * 3 * GRU_H];                                  // partial[ks][b][gate*256+u]
+    const float* __restrict__ bhh1, float* __restrict__ y, int B, int S, float* __restrict__ gates) {
+    extern __shared__ __attribute__((aligned(16))) float glds[];
+    float4* wl4 = reinterpret_cast<float4*>(glds);                   // [NPART][KLDS4][3][256] float4
+    float* hs = glds + GRU_NPART * GRU_KLDS4 * 3 * 256 * 4;          // h[b][k]
+    float* ps = hs + GRU_BW * GRU_H;                                 // partial[part][b][gate*256+u]
     const int dir = blockIdx.y, b0 = blockIdx.x * GRU_BW;
-    const int tid = threadIdx.x, u = tid & 255, ks = tid >> 8;
+    const int tid = threadIdx.x, u = tid & 255, part = tid >> 8;
     const float4* w4 = reinterpret_cast<const float4*>(wt) + (size_t)dir * 64 * 768;
     const float* bhh = dir ? bhh1 : bhh0;
-    const int bme = ks;                                   // utterance this thread finishes
-    const bool bvalid = (b0 + bme) < B;
+    const int kb4 = part * GRU_KPER4;                                // first k/4 group of this part
+    // weights that stay on chip for the whole sequence
+    float4 wr[GRU_KREG4][3];
+#pragma unroll
+    for (int i = 0; i < GRU_KREG4; ++i)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) wr[i][g] = w4[(size_t)(kb4 + i) * 768 + g * 256 + u];
+#pragma unroll
+    for (int i = 0; i < GRU_KLDS4; ++i)
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+            wl4[((part * GRU_KLDS4 + i) * 3 + g) * 256 + u] = w4[(size_t)(kb4 + GRU_KREG4 + i) * 768 + g * 256 + u];
     const float bh_r = bhh[u], bh_z = bhh[256 + u], bh_n = bhh[512 + u];
-    hs[tid] = 0.0f;
-    float hprev = 0.0f;
+    for (int i = tid; i < GRU_BW * GRU_H; i += GRU_THREADS) hs[i] = 0.0f;
+    float hprev[GRU_NQ];
+#pragma unroll
+    for (int q = 0; q < GRU_NQ; ++q) hprev[q] = 0.0f;
     __syncthreads();
     for (int step = 0; step < S; ++step) {
         const int t = dir ? (S - 1 - step) : step;
-        float gr = 0.f, gz = 0.f, gn = 0.f;
-        if (bvalid) {
-            const float* g = gi + ((size_t)(b0 + bme) * S + t) * 1536 + dir * 768;
-            gr = g[u]; gz = g[256 + u]; gn = g[512 + u];
+        float gr[GRU_NQ], gz[GRU_NQ], gn[GRU_NQ];
+#pragma unroll
+        for (int q = 0; q < GRU_NQ; ++q) {
+            const int blq = part + GRU_NPART * q, bq = b0 + blq;
+            gr[q] = gz[q] = gn[q] = 0.0f;
+            if (blq < GRU_BW && bq < B) {
+                const float* g = gi + ((size_t)bq * S + t) * 1536 + dir * 768;
+                gr[q] = g[u]; gz[q] = g[256 + u]; gn[q] = g[512 + u];
+            }
         }
         float acc[3][GRU_BW];
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
             for (int bb = 0; bb < GRU_BW; ++bb) acc[g][bb] = 0.0f;
-#pragma unroll 4
-        for (int k4 = ks * 16; k4 < ks * 16 + 16; ++k4) {
-            const float4 wr = w4[(size_t)k4 * 768 + u];
-            const float4 wz = w4[(size_t)k4 * 768 + 256 + u];
-            const float4 wn = w4[(size_t)k4 * 768 + 512 + u];
+        // streamed part first (its loads fly while the resident parts compute)
+#pragma unroll 2
+        for (int i = 0; i < GRU_KSTR4; ++i) {
+            const int k4 = kb4 + GRU_KREG4 + GRU_KLDS4 + i;
+            const float4 w0 = w4[(size_t)k4 * 768 + u], w1 = w4[(size_t)k4 * 768 + 256 + u], w2 = w4[(size_t)k4 * 768 + 512 + u];
+            float4 h4[GRU_BW];
 #pragma unroll
-            for (int bb = 0; bb < GRU_BW; ++bb) {
-                const float4 h4 = *reinterpret_cast<const float4*>(hs + bb * GRU_H + k4 * 4);
-                acc[0][bb] = fmaf(wr.x, h4.x, acc[0][bb]); acc[0][bb] = fmaf(wr.y, h4.y, acc[0][bb]);
-                acc[0][bb] = fmaf(wr.z, h4.z, acc[0][bb]); acc[0][bb] = fmaf(wr.w, h4.w, acc[0][bb]);
-                acc[1][bb] = fmaf(wz.x, h4.x, acc[1][bb]); acc[1][bb] = fmaf(wz.y, h4.y, acc[1][bb]);
-                acc[1][bb] = fmaf(wz.z, h4.z, acc[1][bb]); acc[1][bb] = fmaf(wz.w, h4.w, acc[1][bb]);
-                acc[2][bb] = fmaf(wn.x, h4.x, acc[2][bb]); acc[2][bb] = fmaf(wn.y, h4.y, acc[2][bb]);
-                acc[2][bb] = fmaf(wn.z, h4.z, acc[2][bb]); acc[2][bb] = fmaf(wn.w, h4.w, acc[2][bb]);
-            }
+            for (int bb = 0; bb < GRU_BW; ++bb) h4[bb] = *reinterpret_cast<const float4*>(hs + bb * GRU_H + k4 * 4);
+            gru_fma4(acc[0], w0, h4); gru_fma4(acc[1], w1, h4); gru_fma4(acc[2], w2, h4);
+        }
+#pragma unroll
+        for (int i = 0; i < GRU_KREG4; ++i) {
+            float4 h4[GRU_BW];
+#pragma unroll
+            for (int bb = 0; bb < GRU_BW; ++bb) h4[bb] = *reinterpret_cast<const float4*>(hs + bb * GRU_H + (kb4 + i) * 4);
+            gru_fma4(acc[0], wr[i][0], h4); gru_fma4(acc[1], wr[i][1], h4); gru_fma4(acc[2], wr[i][2], h4);
+        }
+#pragma unroll
+        for (int i = 0; i < GRU_KLDS4; ++i) {
+            float4 h4[GRU_BW];
+#pragma unroll
+            for (int bb = 0; bb < GRU_BW; ++bb)
+                h4[bb] = *reinterpret_cast<const float4*>(hs + bb * GRU_H + (kb4 + GRU_KREG4 + i) * 4);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gru_fma4(acc[g], wl4[((part * GRU_KLDS4 + i) * 3 + g) * 256 + u], h4);
         }
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-            for (int bb = 0; bb < GRU_BW; ++bb) ps[((ks * GRU_BW + bb) * 3 + g) * GRU_H + u] = acc[g][bb];
+            for (int bb = 0; bb < GRU_BW; ++bb) ps[((part * GRU_BW + bb) * 3 + g) * GRU_H + u] = acc[g][bb];
         __syncthreads();
-        float hr = bh_r, hz = bh_z, hn = bh_n;
+        float hnew[GRU_NQ];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            hr += ps[((s * GRU_BW + bme) * 3 + 0) * GRU_H + u];
-            hz += ps[((s * GRU_BW + bme) * 3 + 1) * GRU_H + u];
-            hn += ps[((s * GRU_BW + bme) * 3 + 2) * GRU_H + u];
-        }
-        const float r = sigmoidf_(gr + hr);
-        const float zg = sigmoidf_(gz + hz);
-        const float nn = tanhf(gn + r * hn);
-        const float hnew = (1.0f - zg) * nn + zg * hprev;
-        hprev = hnew;
-        hs[bme * GRU_H + u] = hnew;
-        if (bvalid) {
-            y[((size_t)(b0 + bme) * S + t) * 512 + dir * 256 + u] = hnew;
-            if (SAVE) {
-                float* gs = gates + (((size_t)(b0 + bme) * S + t) * 2 + dir) * 1024;
-                gs[u] = r; gs[256 + u] = zg; gs[512 + u] = nn; gs[768 + u] = hn;
+        for (int q = 0; q < GRU_NQ; ++q) {
+            const int bl = part + GRU_NPART * q;
+            hnew[q] = 0.0f;
+            if (bl >= GRU_BW) continue;
+            float hr = bh_r, hz = bh_z, hn = bh_n;
+#pragma unroll
+            for (int pp = 0; pp < GRU_NPART; ++pp) {
+                hr += ps[((pp * GRU_BW + bl) * 3 + 0) * GRU_H + u];
+                hz += ps[((pp * GRU_BW + bl) * 3 + 1) * GRU_H + u];
+                hn += ps[((pp * GRU_BW + bl) * 3 + 2) * GRU_H + u];
+            }
+            const float r = sigmoidf_(gr[q] + hr);
+            const float zg = sigmoidf_(gz[q] + hz);
+            const float nn = tanhf(gn[q] + r * hn);
+            hnew[q] = (1.0f - zg) * nn + zg * hprev[q];
+            hprev[q] = hnew[q];
+            if (b0 + bl < B) {
+                y[((size_t)(b0 + bl) * S + t) * 512 + dir * 256 + u] = hnew[q];
+                if (SAVE) {
+                    float* gs = gates + (((size_t)(b0 + bl) * S + t) * 2 + dir) * 1024;
+                    gs[u] = r; gs[256 + u] = zg; gs[512 + u] = nn; gs[768 + u] = hn;
+                }
             }
         }
+        __syncthreads();                       // every partial consumed, every old h read
+#pragma unroll
+        for (int q = 0; q < GRU_NQ; ++q)
+            if (part + GRU_NPART * q < GRU_BW) hs[(part + GRU_NPART * q) * GRU_H + u] = hnew[q];
         __syncthreads();
     }
 }
@@ -462,8 +534,15 @@ constexpr int ATT_MAX_S = 256;
 
 static __global__ __launch_bounds__(256) void attention_pool_kernel(const float* __restrict__ y, const float* __restrict__ aw,
                                                              const float* __restrict__ ab, float* __restrict__ ctx,
-                                                             int S) {
+                                                             int S, const float* __restrict__ fcw,
+                                                             const float* __restrict__ fcb, int C,
+                                                             float* __restrict__ logits, long long* __restrict__ amax) {
+    // fused tail (models.py:63-67 + evaluate.py:83): attention pooling, the 512 -> C classifier and the
+    // arg-max of one utterance per workgroup.  The head is 31.7 kFLOP per utterance; as a separate
+    // 128x64-tile MFMA GEMM it occupied 2 workgroups and cost 34 us per batch, fused here it is free.
     __shared__ float sc[ATT_MAX_S];
+    __shared__ float cs[512];
+    __shared__ float lg[64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* yb = y + (size_t)b * S * 512;
     float a[8];
@@ -486,6 +565,30 @@ static __global__ __launch_bounds__(256) void attention_pool_kernel(const float*
         float acc = 0.0f;
         for (int t = 0; t < S; ++t) acc = fmaf(expf(sc[t] - mx) / den, yb[(size_t)t * 512 + c], acc);
         ctx[(size_t)b * 512 + c] = acc;
+        cs[c] = acc;
+    }
+    if (!logits) return;
+    __syncthreads();
+    for (int j = wv; j < C; j += 4) {
+        float d = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d = fmaf(cs[lane + 64 * i], fcw[(size_t)j * 512 + lane + 64 * i], d);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+        if (lane == 0) {
+            d += fcb[j];
+            lg[j] = d;
+            logits[(size_t)b * C + j] = d;
+        }
+    }
+    if (!amax) return;
+    __syncthreads();
+    if (tid == 0) {
+        float best = lg[0];
+        int bi = 0;
+        for (int c = 1; c < C; ++c)
+            if (lg[c] > best) { best = lg[c]; bi = c; }      // first maximum, as torch.argmax
+        amax[b] = bi;
     }
 }
 

@@ -33,7 +33,7 @@ bool make_tdims(int batch, int t, TDims* d) {
     d->c1gx = ((t + 1) / 2 + C1_PCOLS - 1) / C1_PCOLS;
     d->c1gy = (32 + C1_PROWS - 1) / C1_PROWS;
     d->c2gx = (d->wp1 + 7) / 8;
-    d->c3gx = (d->wp2 + 15) / 16;
+    d->c3gx = (d->wp2 + 7) / 8;                        // conv3-shaped kernels use one patch per wave (2 x 2 patches)
     d->wg2_rb = 16; d->wg3_rb = 8;                     // rows per workgroup of the weight-gradient kernels
     d->wg2_blocks = batch * (32 / d->wg2_rb);
     d->wg3_blocks = batch * (16 / d->wg3_rb);
@@ -205,8 +205,8 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
                            scale + 32, shift + 32, p.a2, B, 32, d.wp1, 64, 16, d.wp2);
     }
     {
-        constexpr size_t lds = (size_t)(8 * 2 + 2) * (4 * 4 + 2) * 36 * 4;
-        hipLaunchKernelGGL((conv3x3_mfma_kernel<64, 128, 2, 4, 2>), dim3(d.c3gx, 1, B), dim3(256), lds, st, p.a2, p.wp3,
+        constexpr size_t lds = (size_t)(8 * 2 + 2) * (4 * 2 + 2) * 36 * 4;
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<64, 128, 2, 2, 2, 1>), dim3(d.c3gx, 1, B), dim3(256), lds, st, p.a2, p.wp3,
                            (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats);
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, d.c3gx * B, 128,
                            (double)B * 16 * d.wp2, w->bn_w[2], w->bn_b[2], bn_running_mean[2], bn_running_var[2], bn_momentum,
@@ -219,9 +219,14 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     const int M = B * S;
     const dim3 ggrid(768 / GB_N, (M + GB_M - 1) / GB_M, 2);
     const dim3 rgrid((B + GRU_BW - 1) / GRU_BW, 2);
-    hipLaunchKernelGGL(gemm_nt_bias_kernel, ggrid, dim3(256), 0, st, p.x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
+    static bool gru_attr = false;
+    if (!gru_attr) {
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_recurrence_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU_LDS_BYTES));
+        gru_attr = true;
+    }
+    hipLaunchKernelGGL(gemm_nt_bias_kernel<32>, ggrid, dim3(256), 0, st, p.x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
                        w->gru_b_ih[0], w->gru_b_ih[1], p.gi, 1536, M, 768, 1024);
-    hipLaunchKernelGGL(gru_recurrence_kernel<true>, rgrid, dim3(1024), 0, st, p.gi, p.wht, w->gru_b_hh[0], w->gru_b_hh[1],
+    hipLaunchKernelGGL(gru_recurrence_kernel<true>, rgrid, dim3(GRU_THREADS), GRU_LDS_BYTES, st, p.gi, p.wht, w->gru_b_hh[0], w->gru_b_hh[1],
                        p.y0, B, S, p.g0);
     const float* y0in = p.y0;
     if (dropout_p > 0.0f) {
@@ -229,13 +234,12 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
                            dropout_p, (unsigned long long)dropout_seed);
         y0in = p.y0d;
     }
-    hipLaunchKernelGGL(gemm_nt_bias_kernel, ggrid, dim3(256), 0, st, y0in, 512, w->gru_w_ih[2], w->gru_w_ih[3], 512,
+    hipLaunchKernelGGL(gemm_nt_bias_kernel<32>, ggrid, dim3(256), 0, st, y0in, 512, w->gru_w_ih[2], w->gru_w_ih[3], 512,
                        w->gru_b_ih[2], w->gru_b_ih[3], p.gi, 1536, M, 768, 512);
-    hipLaunchKernelGGL(gru_recurrence_kernel<true>, rgrid, dim3(1024), 0, st, p.gi, p.wht + (size_t)2 * 768 * 256,
+    hipLaunchKernelGGL(gru_recurrence_kernel<true>, rgrid, dim3(GRU_THREADS), GRU_LDS_BYTES, st, p.gi, p.wht + (size_t)2 * 768 * 256,
                        w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1);
-    hipLaunchKernelGGL(attention_pool_kernel, dim3(B), dim3(256), 0, st, p.y1, w->attn_w, w->attn_b, p.ctx, S);
-    hipLaunchKernelGGL(gemm_nt_bias_kernel, dim3((w->num_classes + GB_N - 1) / GB_N, (B + GB_M - 1) / GB_M, 1), dim3(256), 0, st,
-                       p.ctx, 512, w->fc_w, w->fc_w, 512, w->fc_b, w->fc_b, logits, w->num_classes, B, w->num_classes, 512);
+    hipLaunchKernelGGL(attention_pool_kernel, dim3(B), dim3(256), 0, st, p.y1, w->attn_w, w->attn_b, p.ctx, S, w->fc_w,
+                       w->fc_b, w->num_classes, logits, (long long*)nullptr);
     KCHECK();
     return SIR_OK;
 }
@@ -305,7 +309,7 @@ extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, co
         const float* yout = layer ? p.y1 : p.y0;
         const float* xin = layer ? y0in : p.x0;
         const int in_sz = layer ? 512 : 1024;
-        hipLaunchKernelGGL(gru_bwd_kernel, rgrid, dim3(1024), 0, st, dy, gates, yout, (const float*)(p.wr4 + (size_t)2 * layer * 768 * 256),
+        hipLaunchKernelGGL(gru_bwd_kernel, dim3((B + GRU_BBW - 1) / GRU_BBW, 2), dim3(1024), 0, st, dy, gates, yout, (const float*)(p.wr4 + (size_t)2 * layer * 768 * 256),
                            p.dgi, p.dgh, bsum_i, bsum_h, B, S);
         for (int dir = 0; dir < 2; ++dir) {      // bias gradients first: bsum_* alias the slab area used below
             const int gi_idx = 2 * layer + dir;
@@ -354,8 +358,8 @@ extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, co
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 128 * 64 + 255) / 256), dim3(256), 0, st, (const float*)p.slab,
                            d.wg3_blocks, 64, 128, g->conv_w[2]);
         hipLaunchKernelGGL(prep_conv_wT_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], p.wp3t, 64, 128);
-        constexpr size_t ldsd = (size_t)(8 * 2 + 2) * (4 * 4 + 2) * 36 * 4;
-        hipLaunchKernelGGL((conv3x3_mfma_kernel<128, 64, 2, 4, 2>), dim3(d.c3gx, 1, B), dim3(256), ldsd, st, (const float*)p.dz3,
+        constexpr size_t ldsd = (size_t)(8 * 2 + 2) * (4 * 2 + 2) * 36 * 4;
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<128, 64, 2, 2, 2, 1>), dim3(d.c3gx, 1, B), dim3(256), ldsd, st, (const float*)p.dz3,
                            (const float*)p.wp3t, (const float*)nullptr, (const float*)nullptr, p.da2, 16, d.wp2, 8, d.wp3,
                            (float2*)nullptr);
         KCHECK();

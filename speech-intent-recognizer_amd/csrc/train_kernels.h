@@ -313,6 +313,7 @@ static __global__ void prep_whh_bwd_kernel(const float* __restrict__ w, float* _
     wr4[idx] = w[(size_t)(r4 * 4 + e) * 256 + k];
 }
 
+constexpr int GRU_BBW = 4;      // utterances per workgroup of the backward recurrence
 static __global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ gates,
                                                         const float* __restrict__ y, const float* __restrict__ wr4,
                                                         float* __restrict__ dgi, float* __restrict__ dgh,
@@ -320,9 +321,9 @@ static __global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __res
                                                         int S) {
     // bsum_i / bsum_h [B][1536]: per-utterance sums over time of dgi / dgh (bias gradients are their
     // column sums over B rows instead of B*S rows)
-    __shared__ __attribute__((aligned(16))) float gsh[GRU_BW * 768];       // dgh[b][row]
-    __shared__ float ps[4 * GRU_BW * GRU_H];                               // partial[rs][b][k]
-    const int dir = blockIdx.y, b0 = blockIdx.x * GRU_BW;
+    __shared__ __attribute__((aligned(16))) float gsh[GRU_BBW * 768];       // dgh[b][row]
+    __shared__ float ps[4 * GRU_BBW * GRU_H];                               // partial[rs][b][k]
+    const int dir = blockIdx.y, b0 = blockIdx.x * GRU_BBW;
     const int tid = threadIdx.x, u = tid & 255, ks = tid >> 8;
     const int bme = ks;
     const bool bvalid = (b0 + bme) < B;
@@ -354,24 +355,24 @@ static __global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __res
         }
         gsh[bme * 768 + u] = drp; gsh[bme * 768 + 256 + u] = dzp; gsh[bme * 768 + 512 + u] = dnr;
         __syncthreads();
-        float acc[GRU_BW];
+        float acc[GRU_BBW];
 #pragma unroll
-        for (int bb = 0; bb < GRU_BW; ++bb) acc[bb] = 0.0f;
+        for (int bb = 0; bb < GRU_BBW; ++bb) acc[bb] = 0.0f;
 #pragma unroll 4
         for (int r4 = ks * 48; r4 < ks * 48 + 48; ++r4) {
             const float4 wv = w4[(size_t)r4 * 256 + u];
 #pragma unroll
-            for (int bb = 0; bb < GRU_BW; ++bb) {
+            for (int bb = 0; bb < GRU_BBW; ++bb) {
                 const float4 g4 = *reinterpret_cast<const float4*>(gsh + bb * 768 + r4 * 4);
                 acc[bb] = fmaf(wv.x, g4.x, acc[bb]); acc[bb] = fmaf(wv.y, g4.y, acc[bb]);
                 acc[bb] = fmaf(wv.z, g4.z, acc[bb]); acc[bb] = fmaf(wv.w, g4.w, acc[bb]);
             }
         }
 #pragma unroll
-        for (int bb = 0; bb < GRU_BW; ++bb) ps[(ks * GRU_BW + bb) * GRU_H + u] = acc[bb];
+        for (int bb = 0; bb < GRU_BBW; ++bb) ps[(ks * GRU_BBW + bb) * GRU_H + u] = acc[bb];
         __syncthreads();
-        dh_carry = dhz + ps[(0 * GRU_BW + bme) * GRU_H + u] + ps[(1 * GRU_BW + bme) * GRU_H + u] +
-                   ps[(2 * GRU_BW + bme) * GRU_H + u] + ps[(3 * GRU_BW + bme) * GRU_H + u];
+        dh_carry = dhz + ps[(0 * GRU_BBW + bme) * GRU_H + u] + ps[(1 * GRU_BBW + bme) * GRU_H + u] +
+                   ps[(2 * GRU_BBW + bme) * GRU_H + u] + ps[(3 * GRU_BBW + bme) * GRU_H + u];
         __syncthreads();
     }
     if (bvalid) {
