@@ -1,5 +1,6 @@
 // sir_model_infer: eval-mode CNNAudioGRU.forward + argmax (models/models.py:41-68, scripts/evaluate.py:82-83)
 // as a fixed sequence of hand-written kernels on one stream.  See model_kernels.h for the kernels.
+#include <stdlib.h>
 #include "model_kernels.h"
 
 namespace {
@@ -126,17 +127,35 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     { SirProfScope prof(h, SIR_K_CONV1, st);
     hipLaunchKernelGGL(conv1_bn_relu_pool_kernel, dim3((d.wp1 + C1_PCOLS - 1) / C1_PCOLS, (32 + C1_PROWS - 1) / C1_PROWS, B),
                        dim3(256), 0, st, feats, w->conv_w[0], bns, bnt, a1, 64, d.T, 32, d.wp1); }
+    static const int conv2_variant = getenv("SIR_CONV2_VARIANT") ? atoi(getenv("SIR_CONV2_VARIANT")) : 0;   // A/B switch
     {
         SirProfScope prof(h, SIR_K_CONV2, st);
-        constexpr size_t lds = (size_t)(8 * 4 + 2) * (4 * 2 + 2) * 36 * 4;
-        hipLaunchKernelGGL((conv3x3_mfma_kernel<32, 64, 4, 2, 0, 2>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), lds, st, a1, wp2,
-                           bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
+        if (conv2_variant == 0) {
+            constexpr size_t lds = (size_t)(8 * 4 + 2) * (4 * 2 + 2) * 36 * 4;
+            hipLaunchKernelGGL((conv3x3_mfma_kernel<32, 64, 4, 2, 0, 2>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), lds, st, a1, wp2,
+                               bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
+        } else if (conv2_variant == 1) {
+            constexpr size_t lds = (size_t)(8 * 4 + 2) * (4 * 2 + 2) * 20 * 4;
+            hipLaunchKernelGGL((conv3x3_mfma_kernel<32, 64, 4, 2, 0, 2, 16>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), lds, st, a1, wp2,
+                               bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
+        } else {
+            constexpr size_t lds = (size_t)(8 * 2 + 2) * (4 * 4 + 2) * 36 * 4;
+            hipLaunchKernelGGL((conv3x3_mfma_kernel<32, 64, 2, 4, 0, 2>), dim3((d.wp1 + 15) / 16, 2, B), dim3(256), lds, st, a1, wp2,
+                               bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
+        }
     }
     {
         SirProfScope prof(h, SIR_K_CONV3, st);
+        static const int conv3_variant = getenv("SIR_CONV3_VARIANT") ? atoi(getenv("SIR_CONV3_VARIANT")) : 0;
+        if (conv3_variant == 0) {
         constexpr size_t lds = (size_t)(8 * 2 + 2) * (4 * 2 + 2) * 36 * 4;
         hipLaunchKernelGGL((conv3x3_mfma_kernel<64, 128, 2, 2, 1, 1>), dim3((d.wp2 + 7) / 8, 1, B), dim3(256), lds, st, a2, wp3,
                            bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)nullptr);
+        } else {
+        constexpr size_t lds = (size_t)(8 * 2 + 2) * (4 * 2 + 2) * 20 * 4;
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<64, 128, 2, 2, 1, 1, 16>), dim3((d.wp2 + 7) / 8, 1, B), dim3(256), lds, st, a2, wp3,
+                           bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)nullptr);
+        }
     }
     SIR_KCHECK();
 
@@ -149,14 +168,19 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_recurrence_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU_LDS_BYTES));
         gru_attr = true;
     }
+    static const int gemm_variant = getenv("SIR_GEMM_VARIANT") ? atoi(getenv("SIR_GEMM_VARIANT")) : 1;   // A/B switch
     { SirProfScope prof(h, SIR_K_GEMM_IH0, st);
-    hipLaunchKernelGGL(gemm_nt_bias_kernel<32>, ggrid, dim3(256), 0, st, x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
+    if (gemm_variant == 1)
+    hipLaunchKernelGGL((gemm_nt_bias_kernel<32, true>), ggrid, dim3(256), 0, st, x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
+                       w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024);
+    else
+    hipLaunchKernelGGL((gemm_nt_bias_kernel<32, false>), ggrid, dim3(256), 0, st, x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
                        w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024); }
     { SirProfScope prof(h, SIR_K_GRU0, st);
     hipLaunchKernelGGL(gru_recurrence_kernel<false>, rgrid, dim3(GRU_THREADS), GRU_LDS_BYTES, st, gi, wht, w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S,
                        (float*)nullptr); }
     { SirProfScope prof(h, SIR_K_GEMM_IH1, st);
-    hipLaunchKernelGGL(gemm_nt_bias_kernel<32>, ggrid, dim3(256), 0, st, y0, 512, w->gru_w_ih[2], w->gru_w_ih[3], 512,
+    hipLaunchKernelGGL((gemm_nt_bias_kernel<32, true>), ggrid, dim3(256), 0, st, y0, 512, w->gru_w_ih[2], w->gru_w_ih[3], 512,
                        w->gru_b_ih[2], w->gru_b_ih[3], gi, 1536, M, 768, 512); }
     { SirProfScope prof(h, SIR_K_GRU1, st);
     hipLaunchKernelGGL(gru_recurrence_kernel<false>, rgrid, dim3(GRU_THREADS), GRU_LDS_BYTES, st, gi, wht + (size_t)2 * 768 * 256, w->gru_b_hh[2],

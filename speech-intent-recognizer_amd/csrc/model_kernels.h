@@ -109,12 +109,17 @@ static __global__ __launch_bounds__(256) void conv1_bn_relu_pool_kernel(
 // OUT_MODE 0: NHWC [B][Hp][Wp][COUT];  1: GRU input [B][Wp][COUT*Hp] with feature = co*Hp + py
 //   (the permute(0,3,1,2).view of models/models.py:55-57, folded into the store).
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int PR, int PC, int OUT_MODE, int MT = 2>
+// Measured (round 1, same box A/B): hipcc shrinks this kernel to ~96 VGPRs by sinking each B-operand
+// load next to its use (load, s_waitcnt, 4 MFMAs, ...).  Forcing the source-level prefetch to stay
+// (sched_barrier + amdgpu_waves_per_eu) costs 40+ VGPRs and LOST 15-20 %: with 64-cycle fp32 MFMAs,
+// 5 resident waves per SIMD hide the load latency better than a deeper per-wave pipeline at 3.
+template <int CIN, int COUT, int PR, int PC, int OUT_MODE, int MT = 2, int CK = 32>
 __global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void conv3x3_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp,
     float2* __restrict__ stats = nullptr) {
-    constexpr int NT = COUT / 32, CK = 32, PS = CK + 4;     // MT patches per wave, NT channel tiles
+    constexpr int NT = COUT / 32, PS = CK + 4;              // MT patches per wave, NT channel tiles, CK channels per LDS chunk
+    constexpr int C4 = CK / 4, NIT = (CK / 8) * 9;          // float4 per pixel, (ci-group, tap) iterations per chunk
     constexpr int TR = 8 * PR, TC = 4 * PC, TROWS = TR + 2, TCOLS = TC + 2;
     static_assert(PR * PC == 4 * MT && CIN % CK == 0 && (MT == 1 || PR % 2 == 0), "tile shape");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -149,8 +154,8 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void conv3x3_mfma_kernel(
 
     for (int cc = 0; cc < CIN / CK; ++cc) {
         if (cc) __syncthreads();
-        for (int idx = tid; idx < TROWS * TCOLS * 8; idx += 256) {
-            const int pix = idx >> 3, part = idx & 7;
+        for (int idx = tid; idx < TROWS * TCOLS * C4; idx += 256) {
+            const int pix = idx / C4, part = idx % C4;
             const int tyy = pix / TCOLS, txx = pix - tyy * TCOLS;
             const int gy = ty0 - 1 + tyy, gx = tx0 - 1 + txx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -161,13 +166,13 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void conv3x3_mfma_kernel(
         __syncthreads();
         if (!pvalid[0]) continue;                 // wave-uniform: this wave's patches lie beyond W
         float4 bcur[NT], bnxt[NT];
-        const int g0 = cc * 36;
+        const int g0 = cc * NIT;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bcur[nt] = wp4[((size_t)g0 * COUT + nt * 32 + m) * 2 + kh];
 #pragma unroll
-        for (int it = 0; it < 36; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int cgl = it / 9, tap = it % 9, ky = tap / 3, kx = tap % 3;
-            if (it + 1 < 36) {
+            if (it + 1 < NIT) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bnxt[nt] = wp4[((size_t)(g0 + it + 1) * COUT + nt * 32 + m) * 2 + kh];
             }
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void conv3x3_mfma_kernel(
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bcur[nt].w, acc[mt][nt], 0, 0, 0);
                 }
             }
-            if (it + 1 < 36) {
+            if (it + 1 < NIT) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bcur[nt] = bnxt[nt];
             }
@@ -287,8 +292,8 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void conv3x3_mfma_kernel(
 constexpr int GB_M = 128, GB_N = 64, GB_K = 32, GB_S = GB_K + 4;     // general (backward) GEMM tile
 // forward NT GEMM, templated on the K-tile depth GF_K (32 measured faster than 64: more workgroups
 // per CU beat fewer barriers)
-template <int GF_K>
-__global__ __launch_bounds__(256) void gemm_nt_bias_kernel(
+template <int GF_K, bool HOIST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void gemm_nt_bias_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ B0, const float* __restrict__ B1, int ldb,
     const float* __restrict__ bias0, const float* __restrict__ bias1, float* __restrict__ C, int ldc,
     int M, int N, int K) {
@@ -344,11 +349,23 @@ __global__ __launch_bounds__(256) void gemm_nt_bias_kernel(
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) load_tile(kt + 1);
+        float4 fa0[GF_K / 8], fa1[GF_K / 8], fb[GF_K / 8];
+        if (HOIST) {
+            // all operand fragments of the k-tile first (one exposed LDS latency per tile instead of one
+            // per 16 MFMAs), pinned above the MFMAs
+#pragma unroll
+            for (int kk = 0; kk < GF_K / 8; ++kk) {
+                fa0[kk] = *reinterpret_cast<const float4*>(As + (wm * 64 + m) * GF_S + kk * 8 + kh * 4);
+                fa1[kk] = *reinterpret_cast<const float4*>(As + (wm * 64 + 32 + m) * GF_S + kk * 8 + kh * 4);
+                fb[kk] = *reinterpret_cast<const float4*>(Bs + (wn * 32 + m) * GF_S + kk * 8 + kh * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int kk = 0; kk < GF_K / 8; ++kk) {
-            const float4 a0 = *reinterpret_cast<const float4*>(As + (wm * 64 + m) * GF_S + kk * 8 + kh * 4);
-            const float4 a1 = *reinterpret_cast<const float4*>(As + (wm * 64 + 32 + m) * GF_S + kk * 8 + kh * 4);
-            const float4 bq = *reinterpret_cast<const float4*>(Bs + (wn * 32 + m) * GF_S + kk * 8 + kh * 4);
+            const float4 a0 = HOIST ? fa0[kk] : *reinterpret_cast<const float4*>(As + (wm * 64 + m) * GF_S + kk * 8 + kh * 4);
+            const float4 a1 = HOIST ? fa1[kk] : *reinterpret_cast<const float4*>(As + (wm * 64 + 32 + m) * GF_S + kk * 8 + kh * 4);
+            const float4 bq = HOIST ? fb[kk] : *reinterpret_cast<const float4*>(Bs + (wn * 32 + m) * GF_S + kk * 8 + kh * 4);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bq.x, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bq.x, acc[1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bq.y, acc[0], 0, 0, 0);

@@ -224,7 +224,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_recurrence_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU_LDS_BYTES));
         gru_attr = true;
     }
-    hipLaunchKernelGGL(gemm_nt_bias_kernel<32>, ggrid, dim3(256), 0, st, p.x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
+    hipLaunchKernelGGL((gemm_nt_bias_kernel<32, true>), ggrid, dim3(256), 0, st, p.x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
                        w->gru_b_ih[0], w->gru_b_ih[1], p.gi, 1536, M, 768, 1024);
     hipLaunchKernelGGL(gru_recurrence_kernel<true>, rgrid, dim3(GRU_THREADS), GRU_LDS_BYTES, st, p.gi, p.wht, w->gru_b_hh[0], w->gru_b_hh[1],
                        p.y0, B, S, p.g0);
@@ -234,7 +234,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
                            dropout_p, (unsigned long long)dropout_seed);
         y0in = p.y0d;
     }
-    hipLaunchKernelGGL(gemm_nt_bias_kernel<32>, ggrid, dim3(256), 0, st, y0in, 512, w->gru_w_ih[2], w->gru_w_ih[3], 512,
+    hipLaunchKernelGGL((gemm_nt_bias_kernel<32, true>), ggrid, dim3(256), 0, st, y0in, 512, w->gru_w_ih[2], w->gru_w_ih[3], 512,
                        w->gru_b_ih[2], w->gru_b_ih[3], p.gi, 1536, M, 768, 512);
     hipLaunchKernelGGL(gru_recurrence_kernel<true>, rgrid, dim3(GRU_THREADS), GRU_LDS_BYTES, st, p.gi, p.wht + (size_t)2 * 768 * 256,
                        w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1);
