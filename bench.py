@@ -34,6 +34,15 @@ T_PAD = 200
 NUM_CLASSES = 31
 N_POOL = 8                       # distinct batches staged in HBM (8 x 49 MB > the 256 MB MALL)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: bf16 MFMA, dense (no sparsity)
+# kernels that compute their fp32 contraction as 6 bf16 MFMA products per fp32 product ("bf16x6",
+# csrc/bf16x6_kernels.h): the matrix pipe executes 6x the algorithmic FLOPs, so the peak for
+# ALGORITHMIC fp32 FLOP/s on that path is 2500/6 TFLOP/s
+BF16X6_KERNELS = set()
+if int(os.environ.get("SIR_CONV_BF16X6", "1")):
+    BF16X6_KERNELS |= {"conv2_mfma_bn_relu_pool", "conv3_mfma_bn_relu_pool"}
+if int(os.environ.get("SIR_GEMM_VARIANT", "2")) == 2:
+    BF16X6_KERNELS |= {"gemm_ih_l0", "gemm_ih_l1"}
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
 
 # algorithmic work per utterance at T = 200 frames
@@ -76,6 +85,20 @@ def host_cpu_share(cap=16):
         except Exception:
             pass
     return max(1, min(n, cap, int(os.environ.get("SIR_BENCH_CPU_THREADS", cap))))
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc pass (profiles/*/pmc_traffic.json,
+    written by scripts_gpu_pmc.sh + tools in profiles/), or None when no measurement is on file."""
+    try:
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")))
+        if not files:
+            return None
+        with open(files[-1]) as f:
+            return json.load(f).get(kernel)
+    except Exception:
+        return None
 
 
 def device_clips(n, length, seed, device):
@@ -279,10 +302,16 @@ def main():
         d_ms = dom_ms[dominant]
         if dominant in FLOPS_PER_UTT:
             achieved = FLOPS_PER_UTT[dominant] * BATCH / (d_ms * 1e-3) / 1e12
+            x6 = dominant in BF16X6_KERNELS
+            peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if x6 else PEAK_F32_MFMA_TFLOPS
             roofline = {"kernel": dominant, "bound": "mfma", "achieved": round(achieved, 3),
-                        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                        "traffic": None, "avg_launch_ms": round(d_ms, 5), "launches": dom_cnt[dominant],
-                        "flops_per_launch": FLOPS_PER_UTT[dominant] * BATCH}
+                        "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                        "traffic": pmc_traffic(dominant), "avg_launch_ms": round(d_ms, 5), "launches": dom_cnt[dominant],
+                        "flops_per_launch": FLOPS_PER_UTT[dominant] * BATCH,
+                        "mfma_path": ("bf16x6: fp32 product = 6 bf16 MFMA products, f32 accumulate; peak = 2500/6 "
+                                      "algorithmic TFLOP/s; executed bf16 MFMA rate = 6 x achieved") if x6
+                        else "v_mfma_f32_32x32x2_f32",
+                        "fp32_mfma_peak": PEAK_F32_MFMA_TFLOPS}
         else:
             achieved = FEATURE_BYTES_PER_UTT * BATCH / (d_ms * 1e-3) / 1e9
             roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS,

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 --pmc passes of scripts_gpu_pmc.sh (FETCH_SIZE and WRITE_SIZE, collected in
+separate passes) into HBM bytes per launch for the kernels bench.py reports.
+
+    python profiles/pmc_to_traffic.py gpurun_out/pmc profiles/r01
+
+Corrections per MI355X_MICROARCH.md (HBM / rocprofv3): both counters are in KiB; on gfx950 FETCH_SIZE
+reports half of the bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled; WRITE_SIZE
+is exact for 16-byte streaming stores.  Other access widths are uncalibrated -- treat the numbers as
++-2x evidence of re-read waste, not as exact byte counts.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+NAME_MAP = [
+    ("feat_frames_kernel", "feat_frames"), ("feat_normalise_kernel", "feat_normalise"),
+    ("conv1_bn_relu_pool_kernel", "conv1_bn_relu_pool"),
+    ("conv3x3_bf16x6_kernel<32, 64", "conv2_mfma_bn_relu_pool"), ("conv3x3_bf16x6_kernel<64, 128", "conv3_mfma_bn_relu_pool"),
+    ("conv3x3_mfma_kernel<32, 64", "conv2_mfma_bn_relu_pool"), ("conv3x3_mfma_kernel<64, 128", "conv3_mfma_bn_relu_pool"),
+    ("gemm_nt_bf16x6_kernel", "gemm_ih"), ("gemm_nt_bias_kernel", "gemm_ih"), ("gru_recurrence_kernel", "gru_recurrence"),
+    ("attention_pool_kernel", "attention_pool_fc_argmax"),
+]
+
+
+def main(src, dst):
+    vals = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(src, "*", "pmc_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
+                continue
+            for pat, name in NAME_MAP:
+                if pat in r["Kernel_Name"]:
+                    vals[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    break
+    out = {}
+    for name, cs in vals.items():
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            fetch = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024 * 2
+            write = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024
+            out[name] = {"hbm_bytes_per_launch": int(fetch + write), "read_bytes": int(fetch), "write_bytes": int(write),
+                         "launches_sampled": len(cs["FETCH_SIZE"])}
+    os.makedirs(dst, exist_ok=True)
+    with open(os.path.join(dst, "pmc_traffic.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc", sys.argv[2] if len(sys.argv) > 2 else "profiles/r01")

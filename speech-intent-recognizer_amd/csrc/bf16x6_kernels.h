@@ -1,0 +1,290 @@
+// fp32-accurate contractions on the bf16 matrix cores ("bf16x6").
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate.  An fp32 value splits EXACTLY into
+// three bf16 numbers x = hi + mid + lo (8+8+8 mantissa bits); of the nine cross products of two
+// such splits the six with weight >= 2^-16 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) carry the
+// product to ~2^-24 relative, i.e. fp32 accuracy, and accumulate in the MFMA's f32 accumulator.
+// Six v_mfma_f32_32x32x16_bf16 (K = 16, 32 cycles each) replace eight f32 MFMAs (K = 2, 64 cycles
+// each) per 16-deep K step: 192 vs 512 matrix-pipe cycles.  Operands are split once, outside the
+// GEMM, into three bf16 planes (6 bytes per value).
+#pragma once
+#include "model_kernels.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short bf16_rne(float x) {
+    unsigned int u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_as_f32(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+
+__device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+    h = bf16_rne(x);
+    const float r1 = x - bf16_as_f32(h);          // exact
+    m = bf16_rne(r1);
+    const float r2 = r1 - bf16_as_f32(m);         // exact
+    l = bf16_rne(r2);
+}
+
+// in [rows][K] fp32 (row stride ld_in) -> planes [3][rows][K] bf16; one thread = 8 consecutive k
+static __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ in, int ld_in, unsigned short* __restrict__ out,
+                                                             size_t rows, int K) {
+    const int k8n = K / 8;
+    const size_t total = rows * k8n, plane = rows * (size_t)K;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t row = idx / k8n;
+        const int k8 = idx % k8n;
+        const float4 v0 = *reinterpret_cast<const float4*>(in + row * ld_in + k8 * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(in + row * ld_in + k8 * 8 + 4);
+        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        unsigned short h[8], m[8], l[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) split3(x[i], h[i], m[i], l[i]);
+        auto pack = [](const unsigned short* p) {
+            return make_uint4(p[0] | ((unsigned)p[1] << 16), p[2] | ((unsigned)p[3] << 16), p[4] | ((unsigned)p[5] << 16),
+                              p[6] | ((unsigned)p[7] << 16));
+        };
+        const size_t o = row * K + (size_t)k8 * 8;
+        *reinterpret_cast<uint4*>(out + o) = pack(h);
+        *reinterpret_cast<uint4*>(out + plane + o) = pack(m);
+        *reinterpret_cast<uint4*>(out + 2 * plane + o) = pack(l);
+    }
+}
+
+// C[m][z*N + n] = sum_k A[m][k] * Bz[n][k] + biasz[n] with A, B given as bf16x3 planes.
+//   Ap: [3][M][K], Bp0/Bp1: [3][N][K] (z = blockIdx.z).  128 x 64 tile, BK = 32 (two 16-deep MFMA
+//   steps), 4 waves 2x2, wave tile 64 x 32.  LDS rows are 64 B of data + 16 B pad = 80 B: five 16-byte
+//   slots per row make the ds_read_b128 fragment reads conflict-free.
+constexpr int XB_ROW = 80;                                  // bytes per LDS row
+
+static __global__ __launch_bounds__(256) void gemm_nt_bf16x6_kernel(
+    const unsigned short* __restrict__ Ap, const unsigned short* __restrict__ Bp0, const unsigned short* __restrict__ Bp1,
+    const float* __restrict__ bias0, const float* __restrict__ bias1, float* __restrict__ C, int ldc, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[3 * GB_M * XB_ROW];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * GB_N * XB_ROW];
+    const int z = blockIdx.z;
+    const unsigned short* __restrict__ Bp = z ? Bp1 : Bp0;
+    const float* __restrict__ bias = z ? bias1 : bias0;
+    const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1, m = lane & 31, h = lane >> 5;
+    const size_t planeA = (size_t)M * K, planeB = (size_t)N * K;
+
+    uint4 ra[6], rb[3];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {                       // 3 planes x 128 rows x 4 chunks of 16 B
+            const int idx = tid + 256 * i, p = idx >> 9, row = (idx >> 2) & 127, c = idx & 3;
+            ra[i] = (m0 + row < M) ? *reinterpret_cast<const uint4*>(Ap + p * planeA + (size_t)(m0 + row) * K + kt * 32 + c * 8)
+                                   : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {                       // 3 planes x 64 rows x 4 chunks
+            const int idx = tid + 256 * i, p = idx >> 8, row = (idx >> 2) & 63, c = idx & 3;
+            rb[i] = (n0 + row < N) ? *reinterpret_cast<const uint4*>(Bp + p * planeB + (size_t)(n0 + row) * K + kt * 32 + c * 8)
+                                   : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int idx = tid + 256 * i, p = idx >> 9, row = (idx >> 2) & 127, c = idx & 3;
+            *reinterpret_cast<uint4*>(As + (p * GB_M + row) * XB_ROW + c * 16) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = tid + 256 * i, p = idx >> 8, row = (idx >> 2) & 63, c = idx & 3;
+            *reinterpret_cast<uint4*>(Bs + (p * GB_N + row) * XB_ROW + c * 16) = rb[i];
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+
+    const int nk = K / 32;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a0[3], a1[3], b[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a0[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(As + (p * GB_M + wm * 64 + m) * XB_ROW + ks * 32 + h * 16));
+                a1[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(As + (p * GB_M + wm * 64 + 32 + m) * XB_ROW + ks * 32 + h * 16));
+                b[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + (p * GB_N + wn * 32 + m) * XB_ROW + ks * 32 + h * 16));
+            }
+            // small terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi   (planes: 0 = hi, 1 = mid, 2 = lo)
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[2], b[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[2], b[0], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], b[2], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b[2], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1], b[1], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1], b[1], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1], b[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1], b[0], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], b[1], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b[1], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], b[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b[0], acc[1], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+    const int n = n0 + wn * 32 + m;
+    if (n < N) {
+        const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M) C[(size_t)row * ldc + (size_t)z * N + n] = acc[mt][r] + bv;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv 3x3 + BN + ReLU + 2x2 max-pool as an implicit GEMM on the bf16 matrix cores with the
+// bf16x6 split (same tiling idea as conv3x3_mfma_kernel: M = pixels in 8x4 patches, N = cout,
+// K = (tap, ci); pooling in registers).  The fp32 input tile is split into three bf16 planes while
+// it is staged into LDS (16 input channels per chunk, 48-byte pixel rows); the weights arrive
+// pre-split from prep_conv_w_bf16x3_kernel as wpb[plane][g = ci/16*9 + tap][co][16].
+// ------------------------------------------------------------------------------------------
+static __global__ void prep_conv_w_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin, int cout) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = cin * 9 * cout;
+    if (idx >= total) return;
+    const int e = idx & 15, co = (idx >> 4) % cout, g = (idx >> 4) / cout;
+    const int ci = (g / 9) * 16 + e, tap = g % 9;
+    unsigned short h, m, l;
+    split3(w[((size_t)co * cin + ci) * 9 + tap], h, m, l);
+    wpb[idx] = h;
+    wpb[(size_t)total + idx] = m;
+    wpb[2 * (size_t)total + idx] = l;
+}
+
+template <int CIN, int COUT, int PR, int PC, int OUT_MODE, int MT>
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(
+    const float* __restrict__ x, const unsigned short* __restrict__ wpb, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp) {
+    constexpr int NT = COUT / 32, CK = 16, PSB = 48;
+    constexpr int TR = 8 * PR, TC = 4 * PC, TROWS = TR + 2, TCOLS = TC + 2;
+    constexpr int PLANE = TROWS * TCOLS * PSB;              // bytes per plane
+    constexpr int G = (CIN / 16) * 9;
+    static_assert(PR * PC == 4 * MT && CIN % CK == 0 && (MT == 1 || PR % 2 == 0), "tile shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    const int b = blockIdx.z, ty0 = blockIdx.y * TR, tx0 = blockIdx.x * TC;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const int pxl = (m & 1) + 2 * ((m >> 2) & 1);
+    const int pyl = ((m >> 1) & 1) + 2 * ((m >> 3) & 1) + 4 * ((m >> 4) & 1);
+    int aoff[MT], pr_[MT], pc_[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int pi = MT * wv + mt;
+        pr_[mt] = pi % PR;
+        pc_[mt] = pi / PR;
+        aoff[mt] = ((8 * pr_[mt] + pyl) * TCOLS + 4 * pc_[mt] + pxl) * PSB + h * 16;
+    }
+    const bool wvalid = __builtin_amdgcn_readfirstlane((tx0 + 4 * pc_[0] < W) ? 1 : 0) != 0;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    const uint4* wp4 = reinterpret_cast<const uint4*>(wpb);  // uint4 index = ((p*G + g)*COUT + co)*2 + h
+    const float* xb = x + (size_t)b * H * W * CIN;
+
+    for (int cc = 0; cc < CIN / CK; ++cc) {
+        if (cc) __syncthreads();
+        for (int idx = tid; idx < TROWS * TCOLS * 4; idx += 256) {
+            const int pix = idx >> 2, part = idx & 3;
+            const int tyy = pix / TCOLS, txx = pix - tyy * TCOLS;
+            const int gy = ty0 - 1 + tyy, gx = tx0 - 1 + txx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4*>(xb + ((size_t)gy * W + gx) * CIN + cc * CK + part * 4);
+            unsigned short hh[4], mm[4], ll[4];
+            split3(v.x, hh[0], mm[0], ll[0]); split3(v.y, hh[1], mm[1], ll[1]);
+            split3(v.z, hh[2], mm[2], ll[2]); split3(v.w, hh[3], mm[3], ll[3]);
+            unsigned char* d = ldsb + pix * PSB + part * 8;
+            *reinterpret_cast<uint2*>(d) = make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
+            *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(mm[0] | ((unsigned)mm[1] << 16), mm[2] | ((unsigned)mm[3] << 16));
+            *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
+        }
+        __syncthreads();
+        if (!wvalid) continue;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3, g = cc * 9 + tap;
+            bf16x8 bfr[NT][3], afr[MT][3];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bfr[nt][p] = __builtin_bit_cast(bf16x8, wp4[(((size_t)p * G + g) * COUT + nt * 32 + m) * 2 + h]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    afr[mt][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ldsb + p * PLANE + aoff[mt] + (ky * TCOLS + kx) * PSB));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[mt][2], bfr[nt][0], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[mt][0], bfr[nt][2], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[mt][1], bfr[nt][1], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[mt][1], bfr[nt][0], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[mt][0], bfr[nt][1], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[mt][0], bfr[nt][0], acc[mt][nt], 0, 0, 0);
+                }
+        }
+    }
+    // epilogue: BN (folded) -> ReLU -> 2x2 max over registers 4q..4q+3 -> store (as conv3x3_mfma_kernel)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int PX = (tx0 + 4 * pc_[mt]) / 2 + h;
+        const int PYb = (ty0 + 8 * pr_[mt]) / 2;
+        if (PX >= Wp) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = nt * 32 + m;
+            const float s = scale[co], t = shift[co];
+            float pooled[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v = fmaxf(v, fmaf(acc[mt][nt][4 * q + r], s, t));
+                pooled[q] = v;
+            }
+            if (OUT_MODE == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (PYb + q < Hp) out[(((size_t)b * Hp + PYb + q) * Wp + PX) * COUT + co] = pooled[q];
+            } else {
+                float* o = out + ((size_t)b * Wp + PX) * (COUT * Hp) + (size_t)co * Hp + PYb;
+                if ((Hp & 3) == 0) {
+                    *reinterpret_cast<float4*>(o) = make_float4(pooled[0], pooled[1], pooled[2], pooled[3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (PYb + q < Hp) o[q] = pooled[q];
+                }
+            }
+        }
+    }
+}

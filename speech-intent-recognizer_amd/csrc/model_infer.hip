@@ -1,7 +1,7 @@
 // sir_model_infer: eval-mode CNNAudioGRU.forward + argmax (models/models.py:41-68, scripts/evaluate.py:82-83)
 // as a fixed sequence of hand-written kernels on one stream.  See model_kernels.h for the kernels.
 #include <stdlib.h>
-#include "model_kernels.h"
+#include "bf16x6_kernels.h"
 
 namespace {
 
@@ -17,6 +17,9 @@ enum WsBuf {
     WS_WP3,      // prepared conv3 weights [72][128][8]
     WS_BN,       // folded BN: scale[224] then shift[224] (channels of bn1|bn2|bn3)
     WS_WHT,      // transposed W_hh, [4][64][768][4]
+    WS_XS,       // bf16x3 planes of the current GEMM A operand, [3][B*S][1024] bf16
+    WS_WS,       // bf16x3 planes of W_ih: l0 [2][3][768][1024], l1 [2][3][768][512]
+    WS_WCB,      // bf16x3 planes of the conv2 / conv3 weights
     WS_COUNT
 };
 
@@ -43,6 +46,9 @@ void ws_sizes(const Dims& d, size_t* bytes) {
     bytes[WS_WP3] = (size_t)72 * 128 * 8 * 4;
     bytes[WS_BN] = (size_t)2 * 224 * 4;
     bytes[WS_WHT] = (size_t)4 * 768 * 256 * 4;
+    bytes[WS_XS] = B * d.S * 1024 * 3 * 2;
+    bytes[WS_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512) * 2;
+    bytes[WS_WCB] = ((size_t)3 * 32 * 9 * 64 + (size_t)3 * 64 * 9 * 128) * 2;
 }
 
 size_t ws_layout(const Dims& d, size_t* off) {
@@ -107,8 +113,16 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     float* bns = (float*)(ws + off[WS_BN]);
     float* bnt = bns + 224;
     float* wht = (float*)(ws + off[WS_WHT]);
+    unsigned short* xs = (unsigned short*)(ws + off[WS_XS]);
+    unsigned short* wsl0 = (unsigned short*)(ws + off[WS_WS]);
+    unsigned short* wsl1 = wsl0 + (size_t)2 * 3 * 768 * 1024;
+    unsigned short* wcb2 = (unsigned short*)(ws + off[WS_WCB]);
+    unsigned short* wcb3 = wcb2 + (size_t)3 * 32 * 9 * 64;
     const int B = d.B, S = d.S;
 
+    // GEMM variant: 2 = bf16x6 split on the bf16 matrix cores (default), 1/0 = fp32 MFMA (hoisted / plain)
+    static const int gemm_variant = getenv("SIR_GEMM_VARIANT") ? atoi(getenv("SIR_GEMM_VARIANT")) : 2;
+    static const int conv_bf16 = getenv("SIR_CONV_BF16X6") ? atoi(getenv("SIR_CONV_BF16X6")) : 1;
     // ---- weight preparation -------------------------------------------------------------
     {
     SirProfScope prof(h, SIR_K_PREP, st);
@@ -120,6 +134,16 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
                            bns + bn_o[i], bnt + bn_o[i], bn_c[i]);
     for (int i = 0; i < 4; ++i)
         hipLaunchKernelGGL(prep_whh_kernel, dim3(768), dim3(256), 0, st, w->gru_w_hh[i], wht + (size_t)i * 768 * 256);
+    if (conv_bf16) {
+        hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], wcb2, 32, 64);
+        hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], wcb3, 64, 128);
+    }
+    if (gemm_variant == 2) {
+        for (int dir = 0; dir < 2; ++dir) {
+            hipLaunchKernelGGL(split3_kernel, dim3(384), dim3(256), 0, st, w->gru_w_ih[dir], 1024, wsl0 + (size_t)dir * 3 * 768 * 1024, (size_t)768, 1024);
+            hipLaunchKernelGGL(split3_kernel, dim3(192), dim3(256), 0, st, w->gru_w_ih[2 + dir], 512, wsl1 + (size_t)dir * 3 * 768 * 512, (size_t)768, 512);
+        }
+    }
     }
     SIR_KCHECK();
 
@@ -130,7 +154,11 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     static const int conv2_variant = getenv("SIR_CONV2_VARIANT") ? atoi(getenv("SIR_CONV2_VARIANT")) : 0;   // A/B switch
     {
         SirProfScope prof(h, SIR_K_CONV2, st);
-        if (conv2_variant == 0) {
+        if (conv_bf16) {
+            constexpr size_t lds = (size_t)3 * (8 * 4 + 2) * (4 * 2 + 2) * 48;
+            hipLaunchKernelGGL((conv3x3_bf16x6_kernel<32, 64, 4, 2, 0, 2>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), lds, st, a1,
+                               (const unsigned short*)wcb2, bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2);
+        } else if (conv2_variant == 0) {
             constexpr size_t lds = (size_t)(8 * 4 + 2) * (4 * 2 + 2) * 36 * 4;
             hipLaunchKernelGGL((conv3x3_mfma_kernel<32, 64, 4, 2, 0, 2>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), lds, st, a1, wp2,
                                bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
@@ -147,7 +175,15 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     {
         SirProfScope prof(h, SIR_K_CONV3, st);
         static const int conv3_variant = getenv("SIR_CONV3_VARIANT") ? atoi(getenv("SIR_CONV3_VARIANT")) : 0;
-        if (conv3_variant == 0) {
+        if (conv_bf16 && conv3_variant == 0) {
+        constexpr size_t lds = (size_t)3 * (8 * 2 + 2) * (4 * 4 + 2) * 48;
+        hipLaunchKernelGGL((conv3x3_bf16x6_kernel<64, 128, 2, 4, 1, 2>), dim3((d.wp2 + 15) / 16, 1, B), dim3(256), lds, st, a2,
+                           (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3);
+        } else if (conv_bf16) {
+        constexpr size_t lds = (size_t)3 * (8 * 2 + 2) * (4 * 2 + 2) * 48;
+        hipLaunchKernelGGL((conv3x3_bf16x6_kernel<64, 128, 2, 2, 1, 1>), dim3((d.wp2 + 7) / 8, 1, B), dim3(256), lds, st, a2,
+                           (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3);
+        } else if (conv3_variant == 0) {
         constexpr size_t lds = (size_t)(8 * 2 + 2) * (4 * 2 + 2) * 36 * 4;
         hipLaunchKernelGGL((conv3x3_mfma_kernel<64, 128, 2, 2, 1, 1>), dim3((d.wp2 + 7) / 8, 1, B), dim3(256), lds, st, a2, wp3,
                            bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)nullptr);
@@ -168,9 +204,12 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_recurrence_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU_LDS_BYTES));
         gru_attr = true;
     }
-    static const int gemm_variant = getenv("SIR_GEMM_VARIANT") ? atoi(getenv("SIR_GEMM_VARIANT")) : 1;   // A/B switch
     { SirProfScope prof(h, SIR_K_GEMM_IH0, st);
-    if (gemm_variant == 1)
+    if (gemm_variant == 2) {
+        hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, (const float*)x0, 1024, xs, (size_t)M, 1024);
+        hipLaunchKernelGGL(gemm_nt_bf16x6_kernel, ggrid, dim3(256), 0, st, (const unsigned short*)xs, (const unsigned short*)wsl0,
+                           (const unsigned short*)(wsl0 + (size_t)3 * 768 * 1024), w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024);
+    } else if (gemm_variant == 1)
     hipLaunchKernelGGL((gemm_nt_bias_kernel<32, true>), ggrid, dim3(256), 0, st, x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
                        w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024);
     else
@@ -180,6 +219,11 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     hipLaunchKernelGGL(gru_recurrence_kernel<false>, rgrid, dim3(GRU_THREADS), GRU_LDS_BYTES, st, gi, wht, w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S,
                        (float*)nullptr); }
     { SirProfScope prof(h, SIR_K_GEMM_IH1, st);
+    if (gemm_variant == 2) {
+        hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, (const float*)y0, 512, xs, (size_t)M, 512);
+        hipLaunchKernelGGL(gemm_nt_bf16x6_kernel, ggrid, dim3(256), 0, st, (const unsigned short*)xs, (const unsigned short*)wsl1,
+                           (const unsigned short*)(wsl1 + (size_t)3 * 768 * 512), w->gru_b_ih[2], w->gru_b_ih[3], gi, 1536, M, 768, 512);
+    } else
     hipLaunchKernelGGL((gemm_nt_bias_kernel<32, true>), ggrid, dim3(256), 0, st, y0, 512, w->gru_w_ih[2], w->gru_w_ih[3], 512,
                        w->gru_b_ih[2], w->gru_b_ih[3], gi, 1536, M, 768, 512); }
     { SirProfScope prof(h, SIR_K_GRU1, st);
