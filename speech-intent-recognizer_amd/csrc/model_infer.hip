@@ -20,6 +20,8 @@ enum WsBuf {
     WS_XS,       // bf16x3 planes of the current GEMM A operand, [3][B*S][1024] bf16
     WS_WS,       // bf16x3 planes of W_ih: l0 [2][3][768][1024], l1 [2][3][768][512]
     WS_WCB,      // bf16x3 planes of the conv2 / conv3 weights
+    WS_GXB,      // paired GRU: h exchange buffers [pairs*2][2][2][4][128] f32
+    WS_GFL,      // paired GRU: flags [pairs*2][2] u32 + status word
     WS_COUNT
 };
 
@@ -49,6 +51,8 @@ void ws_sizes(const Dims& d, size_t* bytes) {
     bytes[WS_XS] = B * d.S * 1024 * 3 * 2;
     bytes[WS_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512) * 2;
     bytes[WS_WCB] = ((size_t)3 * 32 * 9 * 64 + (size_t)3 * 64 * 9 * 128) * 2;
+    bytes[WS_GXB] = sir_gru_pair_xbuf_bytes(d.B);
+    bytes[WS_GFL] = sir_gru_pair_flag_bytes(d.B);
 }
 
 size_t ws_layout(const Dims& d, size_t* off) {
@@ -118,22 +122,29 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     unsigned short* wsl1 = wsl0 + (size_t)2 * 3 * 768 * 1024;
     unsigned short* wcb2 = (unsigned short*)(ws + off[WS_WCB]);
     unsigned short* wcb3 = wcb2 + (size_t)3 * 32 * 9 * 64;
+    float* gxb = (float*)(ws + off[WS_GXB]);
+    unsigned int* gfl = (unsigned int*)(ws + off[WS_GFL]);
     const int B = d.B, S = d.S;
 
     // GEMM variant: 2 = bf16x6 split on the bf16 matrix cores (default), 1/0 = fp32 MFMA (hoisted / plain)
     static const int gemm_variant = getenv("SIR_GEMM_VARIANT") ? atoi(getenv("SIR_GEMM_VARIANT")) : 2;
     static const int conv_bf16 = getenv("SIR_CONV_BF16X6") ? atoi(getenv("SIR_CONV_BF16X6")) : 1;
+    // GRU variant: 1 = paired workgroups with W_hh resident on chip (default), 0 = single workgroup streaming W_hh
+    static const int gru_variant = getenv("SIR_GRU_VARIANT") ? atoi(getenv("SIR_GRU_VARIANT")) : 1;
     // ---- weight preparation -------------------------------------------------------------
     {
     SirProfScope prof(h, SIR_K_PREP, st);
-    hipLaunchKernelGGL(prep_conv_w_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], wp2, 32, 64);
-    hipLaunchKernelGGL(prep_conv_w_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], wp3, 64, 128);
+    if (!conv_bf16) {
+        hipLaunchKernelGGL(prep_conv_w_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], wp2, 32, 64);
+        hipLaunchKernelGGL(prep_conv_w_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], wp3, 64, 128);
+    }
     const int bn_c[3] = {32, 64, 128}, bn_o[3] = {0, 32, 96};
     for (int i = 0; i < 3; ++i)
         hipLaunchKernelGGL(prep_bn_kernel, dim3(1), dim3(128), 0, st, w->bn_w[i], w->bn_b[i], w->bn_mean[i], w->bn_var[i],
                            bns + bn_o[i], bnt + bn_o[i], bn_c[i]);
-    for (int i = 0; i < 4; ++i)
-        hipLaunchKernelGGL(prep_whh_kernel, dim3(768), dim3(256), 0, st, w->gru_w_hh[i], wht + (size_t)i * 768 * 256);
+    if (gru_variant == 0)
+        for (int i = 0; i < 4; ++i)
+            hipLaunchKernelGGL(prep_whh_kernel, dim3(768), dim3(256), 0, st, w->gru_w_hh[i], wht + (size_t)i * 768 * 256);
     if (conv_bf16) {
         hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], wcb2, 32, 64);
         hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], wcb3, 64, 128);
@@ -216,6 +227,10 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     hipLaunchKernelGGL((gemm_nt_bias_kernel<32, false>), ggrid, dim3(256), 0, st, x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
                        w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024); }
     { SirProfScope prof(h, SIR_K_GRU0, st);
+    if (gru_variant == 1) {
+        const int rc = sir_launch_gru_pair(st, false, gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S, nullptr, gxb, gfl);
+        if (rc != SIR_OK) return rc;
+    } else
     hipLaunchKernelGGL(gru_recurrence_kernel<false>, rgrid, dim3(GRU_THREADS), GRU_LDS_BYTES, st, gi, wht, w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S,
                        (float*)nullptr); }
     { SirProfScope prof(h, SIR_K_GEMM_IH1, st);
@@ -227,6 +242,10 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     hipLaunchKernelGGL((gemm_nt_bias_kernel<32, true>), ggrid, dim3(256), 0, st, y0, 512, w->gru_w_ih[2], w->gru_w_ih[3], 512,
                        w->gru_b_ih[2], w->gru_b_ih[3], gi, 1536, M, 768, 512); }
     { SirProfScope prof(h, SIR_K_GRU1, st);
+    if (gru_variant == 1) {
+        const int rc = sir_launch_gru_pair(st, false, gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], y1, B, S, nullptr, gxb, gfl);
+        if (rc != SIR_OK) return rc;
+    } else
     hipLaunchKernelGGL(gru_recurrence_kernel<false>, rgrid, dim3(GRU_THREADS), GRU_LDS_BYTES, st, gi, wht + (size_t)2 * 768 * 256, w->gru_b_hh[2],
                        w->gru_b_hh[3], y1, B, S, (float*)nullptr); }
     SIR_KCHECK();

@@ -423,9 +423,10 @@ constexpr size_t GRU_LDS_BYTES =
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-__device__ __forceinline__ void gru_fma4(float (&acc)[GRU_BW], const float4 w, const float4 (&h4)[GRU_BW]) {
+template <int NB>
+__device__ __forceinline__ void gru_fma4(float (&acc)[NB], const float4 w, const float4 (&h4)[NB]) {
 #pragma unroll
-    for (int bb = 0; bb < GRU_BW; ++bb) {
+    for (int bb = 0; bb < NB; ++bb) {
         acc[bb] = fmaf(w.x, h4[bb].x, acc[bb]); acc[bb] = fmaf(w.y, h4[bb].y, acc[bb]);
         acc[bb] = fmaf(w.z, h4[bb].z, acc[bb]); acc[bb] = fmaf(w.w, h4[bb].w, acc[bb]);
     }

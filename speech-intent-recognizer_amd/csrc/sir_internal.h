@@ -73,6 +73,12 @@ static inline size_t sir_align_up(size_t x, size_t a) { return (x + a - 1) / a *
 // model_train.hip
 size_t sir_train_workspace_bytes_impl(int batch, int t_frames);
 
+// gru_pair.hip
+size_t sir_gru_pair_xbuf_bytes(int batch);
+size_t sir_gru_pair_flag_bytes(int batch);
+int sir_launch_gru_pair(hipStream_t st, bool save, const float* gi, const float* whh0, const float* whh1, const float* bhh0,
+                        const float* bhh1, float* y, int B, int S, float* gates, float* xbuf, unsigned int* flags);
+
 // features.hip
 int sir_features_launch(sir_handle* h, const void* wave, int wave_dtype, int64_t wave_stride,
                         const int32_t* lengths, int batch, int max_len, float* out, int t_pad,
