@@ -127,6 +127,11 @@ size_t sir_model_workspace_bytes(const sir_handle* h, int batch, int t_frames, i
  * so that tests can check every stage against the oracle.  Returns the number of buffers. */
 int sir_model_workspace_offsets(const sir_handle* h, int batch, int t_frames, int train,
                                 size_t* offsets, int n);
+/* Optional: tell the library which version of the weights the next sir_model_infer calls will see.  The
+ * derived weight layouts (bf16x3 planes, folded BatchNorm, ...) live in the caller's workspace; when the
+ * version is non-zero and unchanged since the previous call with the same workspace and shape, they are
+ * reused instead of rebuilt (~40 us per call).  0 (the default) = always rebuild. */
+int sir_model_set_weights_version(sir_handle* h, uint64_t version);
 int sir_model_infer(sir_handle* h, const sir_model_weights* w, const float* feats, int batch,
                     int t_frames, float* logits, int64_t* argmax, void* workspace,
                     size_t workspace_bytes, void* stream);

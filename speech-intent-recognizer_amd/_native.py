@@ -55,6 +55,7 @@ SIGNATURES = {
                                    C.c_void_p]),
     "sir_model_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "sir_model_workspace_offsets": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.c_int]),
+    "sir_model_set_weights_version": (C.c_int, [C.c_void_p, C.c_uint64]),
     "sir_model_infer": (C.c_int, [C.c_void_p, C.POINTER(ModelWeights), C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sir_model_train_fwd": (C.c_int, [C.c_void_p, C.POINTER(ModelWeights), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),

@@ -45,6 +45,7 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     }
     sir_handle* h = new sir_handle();
     h->prof_mode = 0; h->prof_only = -1;
+    h->weights_version = 0; h->prep_version = 0; h->prep_ws = nullptr; h->prep_key = -1;
     h->tw512 = nullptr; h->tw1024 = nullptr; h->window = nullptr; h->melw = nullptr; h->mel_start = nullptr;
     h->cfg = *cfg;
     h->cfg.window = nullptr;
@@ -118,6 +119,12 @@ extern "C" int sir_features_fwd(sir_handle* h, const void* wave, int wave_dtype,
                                 void* stream) {
     return sir_features_launch(h, wave, wave_dtype, wave_stride, lengths, batch, max_len, out, t_pad, db_out,
                                workspace, workspace_bytes, aug, (hipStream_t)stream);
+}
+
+extern "C" int sir_model_set_weights_version(sir_handle* h, uint64_t version) {
+    if (!h) { sir_set_error("sir_model_set_weights_version: NULL handle"); return SIR_EINVAL; }
+    h->weights_version = version;
+    return SIR_OK;
 }
 
 // ---- event profiling ------------------------------------------------------------------------

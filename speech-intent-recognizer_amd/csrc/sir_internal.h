@@ -27,6 +27,10 @@ struct sir_handle {
     int prof_only;
     std::vector<SirProfRec> prof_pending;
     std::vector<hipEvent_t> prof_free;
+    // prepared-weight cache key (sir_model_set_weights_version)
+    unsigned long long weights_version, prep_version;
+    const void* prep_ws;
+    long long prep_key;
     sir_feature_config cfg;
     int device;
     // feature tables (device)

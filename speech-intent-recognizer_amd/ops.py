@@ -63,6 +63,23 @@ def cached_weights(mod):
     return cache
 
 
+_weights_epoch = [1]
+
+
+def bump_weights_epoch():
+    """Called by everything that rewrites parameters/buffers behind torch's back (the HIP Adam step, the
+    training forward's running-statistics update), so that cached derived weight layouts are rebuilt."""
+    _weights_epoch[0] += 1
+
+
+def weights_version(mod, keep):
+    """Non-zero fingerprint of the weights: global epoch + torch's in-place version counters + storage."""
+    v = _weights_epoch[0] << 40
+    for t in keep:
+        v += t._version
+    return (v + (id(mod) & 0xFFFFF)) & 0xFFFFFFFFFFFFFFFF or 1
+
+
 class Workspace:
     """Grow-only device scratch, 256-byte aligned (torch's caching allocator aligns to 512)."""
 
@@ -101,6 +118,7 @@ def model_infer(mod, x, workspace, want_argmax=False, debug=None):
     w, keep = cached_weights(mod)
     logits = torch.empty((bsz, w.num_classes), dtype=torch.float32, device=x.device)
     amax = torch.empty((bsz,), dtype=torch.int64, device=x.device) if want_argmax else None
+    lib.sir_model_set_weights_version(h, weights_version(mod, keep))
     rc = lib.sir_model_infer(h, C.byref(w), x.data_ptr(), bsz, t, logits.data_ptr(),
                              amax.data_ptr() if amax is not None else None, ws.data_ptr(), ws.numel(),
                              _native.current_stream_ptr())

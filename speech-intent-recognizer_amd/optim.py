@@ -6,7 +6,7 @@ import ctypes as C
 
 import torch
 
-from . import _native
+from . import _native, ops
 from .featurizer import get_featurizer
 
 
@@ -63,4 +63,5 @@ class FusedAdam(torch.optim.Optimizer):
                                        float(group["betas"][1]), float(group["eps"]), float(group["weight_decay"]),
                                        _native.current_stream_ptr())
                 _native.check(rc, "sir_adam_step")
+        ops.bump_weights_epoch()
         return loss

@@ -87,6 +87,7 @@ class _TrainStep(torch.autograd.Function):
         rc = lib.sir_model_train_fwd(h, C.byref(w), rm, rv, x.data_ptr(), bsz, t, momentum, float(dropout_p), seed,
                                      logits.data_ptr(), ws.data_ptr(), ws.numel(), _native.current_stream_ptr())
         _native.check(rc, "sir_model_train_fwd")
+        ops.bump_weights_epoch()                     # BN running statistics were updated in place
         for i in (1, 2, 3):
             getattr(mod, f"bn{i}").num_batches_tracked.add_(1)
         ctx.mod, ctx.x, ctx.seed, ctx.dropout_p, ctx.ws = mod, x, seed, float(dropout_p), ws
