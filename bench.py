@@ -96,7 +96,7 @@ def pmc_traffic(kernel):
         if not files:
             return None
         with open(files[-1]) as f:
-            return json.load(f).get(kernel)
+            return (json.load(f).get(kernel) or {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
 

@@ -173,10 +173,25 @@ static __global__ void prep_conv_w_bf16x3_kernel(const float* __restrict__ w, un
     wpb[2 * (size_t)total + idx] = l;
 }
 
+// data-gradient weights as bf16x3 planes: roles of the channel axes swapped, taps flipped (cf. prep_conv_wT_kernel);
+// output channels co' = forward INPUT channels, 16-groups over the forward OUTPUT channels
+static __global__ void prep_conv_wT_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin_f, int cout_f) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = cin_f * 9 * cout_f;
+    if (idx >= total) return;
+    const int e = idx & 15, cop = (idx >> 4) % cin_f, g = (idx >> 4) / cin_f;
+    const int co_f = (g / 9) * 16 + e, tap = 8 - (g % 9);
+    unsigned short h, m, l;
+    split3(w[((size_t)co_f * cin_f + cop) * 9 + tap], h, m, l);
+    wpb[idx] = h;
+    wpb[(size_t)total + idx] = m;
+    wpb[2 * (size_t)total + idx] = l;
+}
+
 template <int CIN, int COUT, int PR, int PC, int OUT_MODE, int MT>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpb, const float* __restrict__ scale,
-    const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp) {
+    const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp, float2* __restrict__ stats) {
     constexpr int NT = COUT / 32, CK = 16, PSB = 48;
     constexpr int TR = 8 * PR, TC = 4 * PC, TROWS = TR + 2, TCOLS = TC + 2;
     constexpr int PLANE = TROWS * TCOLS * PSB;              // bytes per plane
@@ -252,6 +267,53 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[mt][0], bfr[nt][0], acc[mt][nt], 0, 0, 0);
                 }
         }
+    }
+    if (OUT_MODE == 2) {
+        // raw epilogue (training forward / data gradient), identical to conv3x3_mfma_kernel's
+        float ssum[NT], ssq[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { ssum[nt] = 0.0f; ssq[nt] = 0.0f; }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int xl = (r & 1) + 2 * h, yl = ((r >> 1) & 1) + 2 * ((r >> 2) & 1) + 4 * ((r >> 3) & 1);
+                const int gy = ty0 + 8 * pr_[mt] + yl, gx = tx0 + 4 * pc_[mt] + xl;
+                if (gy < H && gx < W) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float v = acc[mt][nt][r];
+                        out[(((size_t)b * H + gy) * W + gx) * COUT + nt * 32 + m] = v;
+                        ssum[nt] += v;
+                        ssq[nt] = fmaf(v, v, ssq[nt]);
+                    }
+                }
+            }
+        if (stats) {
+            float* lds = reinterpret_cast<float*>(ldsb);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                ssum[nt] += __shfl_xor(ssum[nt], 32);
+                ssq[nt] += __shfl_xor(ssq[nt], 32);
+            }
+            __syncthreads();
+            if (h == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    lds[(wv * COUT + nt * 32 + m) * 2] = ssum[nt];
+                    lds[(wv * COUT + nt * 32 + m) * 2 + 1] = ssq[nt];
+                }
+            }
+            __syncthreads();
+            const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            for (int c = tid; c < COUT; c += 256) {
+                float s = 0.0f, q = 0.0f;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) { s += lds[(w4 * COUT + c) * 2]; q += lds[(w4 * COUT + c) * 2 + 1]; }
+                stats[blk * COUT + c] = make_float2(s, q);
+            }
+        }
+        return;
     }
     // epilogue: BN (folded) -> ReLU -> 2x2 max over registers 4q..4q+3 -> store (as conv3x3_mfma_kernel)
 #pragma unroll

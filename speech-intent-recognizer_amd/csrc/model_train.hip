@@ -3,6 +3,7 @@
 // (sir_model_train_bwd) and multi-tensor Adam (sir_adam_step).  Replaces the body of
 // train_epoch (scripts/train.py:90-107: forward, criterion, loss.backward(), optimizer.step()).
 #include "train_kernels.h"
+#include "bf16x6_kernels.h"
 
 namespace {
 
@@ -15,6 +16,11 @@ enum TrainBuf {
     TB_DY1, TB_DY0, TB_DGI, TB_DGH, TB_DX0, TB_DZ3, TB_DA2, TB_DZ2, TB_DA1,
     TB_SMALL,     // daw_part [B][512], dab_part [B], conv1 wgrad partials
     TB_SLAB,      // split-K / wgrad partial slabs
+    TB_XS,        // bf16x3 planes of the forward GEMM A operand [3][B*S][1024]
+    TB_WS,        // bf16x3 planes of W_ih (l0 [2][3][768][1024], l1 [2][3][768][512])
+    TB_WCB,       // bf16x3 conv weights: conv2, conv3 forward, then conv2, conv3 data-gradient forms
+    TB_GXB,       // paired GRU exchange granules
+    TB_GFL,       // paired GRU status word
     TB_COUNT
 };
 
@@ -33,7 +39,7 @@ bool make_tdims(int batch, int t, TDims* d) {
     d->c1gx = ((t + 1) / 2 + C1_PCOLS - 1) / C1_PCOLS;
     d->c1gy = (32 + C1_PROWS - 1) / C1_PROWS;
     d->c2gx = (d->wp1 + 7) / 8;
-    d->c3gx = (d->wp2 + 7) / 8;                        // conv3-shaped kernels use one patch per wave (2 x 2 patches)
+    d->c3gx = (d->wp2 + 15) / 16;
     d->wg2_rb = 16; d->wg3_rb = 8;                     // rows per workgroup of the weight-gradient kernels
     d->wg2_blocks = batch * (32 / d->wg2_rb);
     d->wg3_blocks = batch * (16 / d->wg3_rb);
@@ -87,6 +93,11 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     if (s_w2 > slab) slab = s_w2;
     if (s_g > slab) slab = s_g;
     n[TB_SLAB] = slab;
+    n[TB_XS] = (B * S * 1024 * 3 + 1) / 2;                       // ushort count / 2 (sizes are in floats)
+    n[TB_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512 + 1) / 2;
+    n[TB_WCB] = ((size_t)2 * (3 * 32 * 9 * 64 + 3 * 64 * 9 * 128) + 1) / 2;
+    n[TB_GXB] = sir_gru_pair_xbuf_bytes(d.B) / 4;
+    n[TB_GFL] = sir_gru_pair_flag_bytes(d.B) / 4;
 }
 
 size_t tws_layout(const TDims& d, size_t* off) {
@@ -107,6 +118,9 @@ struct TPtrs {
     float *a1, *z2, *a2, *z3, *x0, *gi, *g0, *g1, *y0, *y0d, *y1, *ctx, *bn, *bnb, *wp2, *wp3, *wht, *wr4, *wp2t, *wp3t;
     float *dy1, *dy0, *dgi, *dgh, *dx0, *dz3, *da2, *dz2, *da1, *small, *slab;
     float2* stats;
+    unsigned short *xs, *wsl0, *wsl1, *wcb2, *wcb3, *wcb2t, *wcb3t;
+    float* gxb;
+    unsigned int* gfl;
 };
 
 TPtrs carve(void* ws, const size_t* off) {
@@ -123,6 +137,11 @@ TPtrs carve(void* ws, const size_t* off) {
     p.dgh = (float*)(b + off[TB_DGH]); p.dx0 = (float*)(b + off[TB_DX0]); p.dz3 = (float*)(b + off[TB_DZ3]);
     p.da2 = (float*)(b + off[TB_DA2]); p.dz2 = (float*)(b + off[TB_DZ2]); p.da1 = (float*)(b + off[TB_DA1]);
     p.small = (float*)(b + off[TB_SMALL]); p.slab = (float*)(b + off[TB_SLAB]);
+    p.xs = (unsigned short*)(b + off[TB_XS]);
+    p.wsl0 = (unsigned short*)(b + off[TB_WS]); p.wsl1 = p.wsl0 + (size_t)2 * 3 * 768 * 1024;
+    p.wcb2 = (unsigned short*)(b + off[TB_WCB]); p.wcb3 = p.wcb2 + (size_t)3 * 32 * 9 * 64;
+    p.wcb2t = p.wcb3 + (size_t)3 * 64 * 9 * 128; p.wcb3t = p.wcb2t + (size_t)3 * 32 * 9 * 64;
+    p.gxb = (float*)(b + off[TB_GXB]); p.gfl = (unsigned int*)(b + off[TB_GFL]);
     return p;
 }
 
@@ -177,10 +196,12 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     const int B = d.B, S = d.S, T = d.T;
     float *scale = p.bn, *shift = p.bn + 224, *smean = p.bn + 448, *sinv = p.bn + 672;
 
-    hipLaunchKernelGGL(prep_conv_w_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], p.wp2, 32, 64);
-    hipLaunchKernelGGL(prep_conv_w_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], p.wp3, 64, 128);
-    for (int i = 0; i < 4; ++i)
-        hipLaunchKernelGGL(prep_whh_kernel, dim3(768), dim3(256), 0, st, w->gru_w_hh[i], p.wht + (size_t)i * 768 * 256);
+    hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], p.wcb2, 32, 64);
+    hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], p.wcb3, 64, 128);
+    for (int dir = 0; dir < 2; ++dir) {
+        hipLaunchKernelGGL(split3_kernel, dim3(384), dim3(256), 0, st, w->gru_w_ih[dir], 1024, p.wsl0 + (size_t)dir * 3 * 768 * 1024, (size_t)768, 1024);
+        hipLaunchKernelGGL(split3_kernel, dim3(192), dim3(256), 0, st, w->gru_w_ih[2 + dir], 512, p.wsl1 + (size_t)dir * 3 * 768 * 512, (size_t)768, 512);
+    }
     KCHECK();
 
     // conv1 block: statistics pass (recompute), finalize, then the fused conv+BN+ReLU+pool pass
@@ -195,9 +216,9 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     }
     // conv2 block: raw conv + partial statistics on MFMA, finalize, BN+ReLU+pool
     {
-        constexpr size_t lds = (size_t)(8 * 4 + 2) * (4 * 2 + 2) * 36 * 4;
-        hipLaunchKernelGGL((conv3x3_mfma_kernel<32, 64, 4, 2, 2>), dim3(d.c2gx, 1, B), dim3(256), lds, st, p.a1, p.wp2,
-                           (const float*)nullptr, (const float*)nullptr, p.z2, 32, d.wp1, 16, d.wp2, p.stats);
+        constexpr size_t lds = (size_t)3 * (8 * 4 + 2) * (4 * 2 + 2) * 48;
+        hipLaunchKernelGGL((conv3x3_bf16x6_kernel<32, 64, 4, 2, 2, 2>), dim3(d.c2gx, 1, B), dim3(256), lds, st, (const float*)p.a1,
+                           (const unsigned short*)p.wcb2, (const float*)nullptr, (const float*)nullptr, p.z2, 32, d.wp1, 16, d.wp2, p.stats);
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, d.c2gx * B, 64,
                            (double)B * 32 * d.wp1, w->bn_w[1], w->bn_b[1], bn_running_mean[1], bn_running_var[1], bn_momentum,
                            scale + 32, shift + 32, smean + 32, sinv + 32);
@@ -205,9 +226,9 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
                            scale + 32, shift + 32, p.a2, B, 32, d.wp1, 64, 16, d.wp2);
     }
     {
-        constexpr size_t lds = (size_t)(8 * 2 + 2) * (4 * 2 + 2) * 36 * 4;
-        hipLaunchKernelGGL((conv3x3_mfma_kernel<64, 128, 2, 2, 2, 1>), dim3(d.c3gx, 1, B), dim3(256), lds, st, p.a2, p.wp3,
-                           (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats);
+        constexpr size_t lds = (size_t)3 * (8 * 2 + 2) * (4 * 4 + 2) * 48;
+        hipLaunchKernelGGL((conv3x3_bf16x6_kernel<64, 128, 2, 4, 2, 2>), dim3(d.c3gx, 1, B), dim3(256), lds, st, (const float*)p.a2,
+                           (const unsigned short*)p.wcb3, (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats);
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, d.c3gx * B, 128,
                            (double)B * 16 * d.wp2, w->bn_w[2], w->bn_b[2], bn_running_mean[2], bn_running_var[2], bn_momentum,
                            scale + 96, shift + 96, smean + 96, sinv + 96);
@@ -218,26 +239,22 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
 
     const int M = B * S;
     const dim3 ggrid(768 / GB_N, (M + GB_M - 1) / GB_M, 2);
-    const dim3 rgrid((B + GRU_BW - 1) / GRU_BW, 2);
-    static bool gru_attr = false;
-    if (!gru_attr) {
-        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_recurrence_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU_LDS_BYTES));
-        gru_attr = true;
-    }
-    hipLaunchKernelGGL((gemm_nt_bias_kernel<32, true>), ggrid, dim3(256), 0, st, p.x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
-                       w->gru_b_ih[0], w->gru_b_ih[1], p.gi, 1536, M, 768, 1024);
-    hipLaunchKernelGGL(gru_recurrence_kernel<true>, rgrid, dim3(GRU_THREADS), GRU_LDS_BYTES, st, p.gi, p.wht, w->gru_b_hh[0], w->gru_b_hh[1],
-                       p.y0, B, S, p.g0);
+    hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, (const float*)p.x0, 1024, p.xs, (size_t)M, 1024);
+    hipLaunchKernelGGL(gemm_nt_bf16x6_kernel, ggrid, dim3(256), 0, st, (const unsigned short*)p.xs, (const unsigned short*)p.wsl0,
+                       (const unsigned short*)(p.wsl0 + (size_t)3 * 768 * 1024), w->gru_b_ih[0], w->gru_b_ih[1], p.gi, 1536, M, 768, 1024);
+    rc = sir_launch_gru_pair(st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0, p.gxb, p.gfl);
+    if (rc != SIR_OK) return rc;
     const float* y0in = p.y0;
     if (dropout_p > 0.0f) {
         hipLaunchKernelGGL(dropout_kernel, dim3(grid_for((size_t)M * 512)), dim3(256), 0, st, p.y0, p.y0d, (size_t)M * 512,
                            dropout_p, (unsigned long long)dropout_seed);
         y0in = p.y0d;
     }
-    hipLaunchKernelGGL((gemm_nt_bias_kernel<32, true>), ggrid, dim3(256), 0, st, y0in, 512, w->gru_w_ih[2], w->gru_w_ih[3], 512,
-                       w->gru_b_ih[2], w->gru_b_ih[3], p.gi, 1536, M, 768, 512);
-    hipLaunchKernelGGL(gru_recurrence_kernel<true>, rgrid, dim3(GRU_THREADS), GRU_LDS_BYTES, st, p.gi, p.wht + (size_t)2 * 768 * 256,
-                       w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1);
+    hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, y0in, 512, p.xs, (size_t)M, 512);
+    hipLaunchKernelGGL(gemm_nt_bf16x6_kernel, ggrid, dim3(256), 0, st, (const unsigned short*)p.xs, (const unsigned short*)p.wsl1,
+                       (const unsigned short*)(p.wsl1 + (size_t)3 * 768 * 512), w->gru_b_ih[2], w->gru_b_ih[3], p.gi, 1536, M, 768, 512);
+    rc = sir_launch_gru_pair(st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1, p.gxb, p.gfl);
+    if (rc != SIR_OK) return rc;
     hipLaunchKernelGGL(attention_pool_kernel, dim3(B), dim3(256), 0, st, p.y1, w->attn_w, w->attn_b, p.ctx, S, w->fc_w,
                        w->fc_b, w->num_classes, logits, (long long*)nullptr);
     KCHECK();
@@ -357,10 +374,10 @@ extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, co
                            (const float*)p.a2, p.slab, 16, d.wp2, d.wg3_rb);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 128 * 64 + 255) / 256), dim3(256), 0, st, (const float*)p.slab,
                            d.wg3_blocks, 64, 128, g->conv_w[2]);
-        hipLaunchKernelGGL(prep_conv_wT_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], p.wp3t, 64, 128);
-        constexpr size_t ldsd = (size_t)(8 * 2 + 2) * (4 * 2 + 2) * 36 * 4;
-        hipLaunchKernelGGL((conv3x3_mfma_kernel<128, 64, 2, 2, 2, 1>), dim3(d.c3gx, 1, B), dim3(256), ldsd, st, (const float*)p.dz3,
-                           (const float*)p.wp3t, (const float*)nullptr, (const float*)nullptr, p.da2, 16, d.wp2, 8, d.wp3,
+        hipLaunchKernelGGL(prep_conv_wT_bf16x3_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], p.wcb3t, 64, 128);
+        constexpr size_t ldsd = (size_t)3 * (8 * 2 + 2) * (4 * 4 + 2) * 48;
+        hipLaunchKernelGGL((conv3x3_bf16x6_kernel<128, 64, 2, 4, 2, 2>), dim3(d.c3gx, 1, B), dim3(256), ldsd, st, (const float*)p.dz3,
+                           (const unsigned short*)p.wcb3t, (const float*)nullptr, (const float*)nullptr, p.da2, 16, d.wp2, 8, d.wp3,
                            (float2*)nullptr);
         KCHECK();
     }
@@ -388,10 +405,10 @@ extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, co
                            (const float*)p.a1, p.slab, 32, d.wp1, d.wg2_rb);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 32 + 255) / 256), dim3(256), 0, st, (const float*)p.slab,
                            d.wg2_blocks, 32, 64, g->conv_w[1]);
-        hipLaunchKernelGGL(prep_conv_wT_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], p.wp2t, 32, 64);
-        constexpr size_t ldsd = (size_t)(8 * 4 + 2) * (4 * 2 + 2) * 36 * 4;
-        hipLaunchKernelGGL((conv3x3_mfma_kernel<64, 32, 4, 2, 2>), dim3(d.c2gx, 1, B), dim3(256), ldsd, st, (const float*)p.dz2,
-                           (const float*)p.wp2t, (const float*)nullptr, (const float*)nullptr, p.da1, 32, d.wp1, 16, d.wp2,
+        hipLaunchKernelGGL(prep_conv_wT_bf16x3_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], p.wcb2t, 32, 64);
+        constexpr size_t ldsd = (size_t)3 * (8 * 4 + 2) * (4 * 2 + 2) * 48;
+        hipLaunchKernelGGL((conv3x3_bf16x6_kernel<64, 32, 4, 2, 2, 2>), dim3(d.c2gx, 1, B), dim3(256), ldsd, st, (const float*)p.dz2,
+                           (const unsigned short*)p.wcb2t, (const float*)nullptr, (const float*)nullptr, p.da1, 32, d.wp1, 16, d.wp2,
                            (float2*)nullptr);
         KCHECK();
     }

@@ -2,8 +2,15 @@
 oracle (torch autograd over oracle/model_ref.py) and the reference-generated golden samples
 (tests/golden/model_golden.npz: CNNAudioGRU in train() with gru.dropout = 0, Adam lr 5e-5 wd 1e-4).
 
-Tolerance: fp32 everywhere; gradients are compared per tensor, relative to the tensor's RMS:
-max|a-b| <= 2e-3 * rms(b) + 1e-7 (different summation orders over up to 8*25*... terms)."""
+Tolerance: fp32-level everywhere; gradients are compared per tensor, relative to the tensor's RMS:
+max|a-b| <= 2e-3 * rms(b) + 1e-7 (different summation orders over up to 8*25*... terms).
+
+ReLU/max-pool ties: two correct fp32 forwards differ in the last bits (z2 here: 3e-6 abs on rms 0.73),
+and a 2x2 pooling window whose two largest entries are closer than that routes its gradient to a
+different pixel (train8 has one such window: utterance 7, conv2 channel 35, gap 7e-7).  The stage test
+therefore evaluates the oracle's BACKWARD at the device's conv2/conv3 outputs (model_ref z_override,
+forward stages are still compared without it) and stays at 2e-3; the comparison with the
+reference-generated gradient samples cannot do that and allows 2e-2 on the CNN parameters."""
 import ctypes as C
 
 import numpy as np
@@ -76,12 +83,15 @@ def test_train_forward_backward_stages(sd):
     inp = cases.model_inputs()
     x, y = inp["x_train8"], inp["y_train8"]
     m, logits, loss = _hip_step(sd, x, y)
-    st = {}
-    ref_loss, ref_grads, ref_stats, ref_logits = model_ref.loss_and_grads(sd, x, y, stages=st)
+    st0, st = {}, {}
+    ref_loss, _, ref_stats, ref_logits = model_ref.loss_and_grads(sd, x, y, stages=st0)
     v = _views(m, 8, 200)
     nhwc = lambda t: t.permute(0, 2, 3, 1)
-    fwd = {"a1": nhwc(st["conv1"]), "a2": nhwc(st["conv2"]), "x0": st["gru_in"], "y0": st["gru_l0"], "y1": st["gru_l1"],
-           "ctx": st["ctx"]}
+    nchw = lambda t: t.permute(0, 3, 1, 2)
+    fwd = {"a1": nhwc(st0["conv1"]), "a2": nhwc(st0["conv2"]), "x0": st0["gru_in"], "y0": st0["gru_l0"],
+           "y1": st0["gru_l1"], "ctx": st0["ctx"]}
+    # backward: the oracle differentiates at the device's conv2/conv3 outputs (see the module docstring)
+    _, ref_grads, _, _ = model_ref.loss_and_grads(sd, x, y, stages=st, z_override={2: nchw(v["z2"]), 3: nchw(v["z3"])})
     bwd = {"dy1": st["d_gru_l1"], "dy0": st["d_gru_l0"],
            "dx0": st["d_gru_in"], "da2": nhwc(st["d_conv2"]), "da1": nhwc(st["d_conv1"])}
     report = {}
@@ -121,8 +131,9 @@ def test_train_step_matches_reference_golden(sd, model_golden):
         idx = cases.sample_indices(name, g.numel())
         norm = float(model_golden[f"grad_norm/{name}"])
         rms = norm / np.sqrt(g.numel())
-        assert np.abs(g[idx].numpy() - model_golden[f"grad_samp/{name}"]).max() <= 2e-3 * rms + 1e-7, name
-        assert abs(g.double().norm().item() - norm) <= 1e-3 * norm + 1e-7, name
+        tol = 2e-2 if name.startswith(("conv", "bn")) else 2e-3      # pooling ties, see the module docstring
+        assert np.abs(g[idx].numpy() - model_golden[f"grad_samp/{name}"]).max() <= tol * rms + 1e-7, name
+        assert abs(g.double().norm().item() - norm) <= 0.5 * tol * norm + 1e-7, name
     opt.step()
     torch.cuda.synchronize()
     for name, p in m.named_parameters():
