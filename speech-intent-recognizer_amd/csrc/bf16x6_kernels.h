@@ -154,6 +154,185 @@ static __global__ __launch_bounds__(256) void gemm_nt_bf16x6_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Second generation of the bf16x6 GEMM (same contract as gemm_nt_bf16x6_kernel): 8 waves (two per
+// SIMD), tile 160 rows x 256 columns, BK = 32.  Both operands are staged by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR staging, no ds_write pass) in pieces of 16 rows x 64 B per wave
+// instruction; fragment-shaped register loads of B (32 rows x 16 B per instruction) were tried and
+// cost the vector-memory address path ~28 us per launch.  Stage = A [3][160][64 B] + B [3][256][64 B] = 79,872 B, two stages.
+// Swizzle on the source address: chunk c of row r is stored at chunk c ^ ((r >> 2) & 3) (four 64-B
+// rows share a 256-B bank line), conflict-free for the ds_read_b128 lane groups.  A wave owns a
+// 160 x 32 strip (five accumulators), reads 15 A + 3 B fragments per 16-deep step for 30 MFMAs; the
+// second wave on the SIMD covers the LDS latency.  The next tile's DMA pieces are issued between
+// the MFMAs (a piece costs the issuing wave ~100 cycles): waves 0-3 during step 0, their SIMD partners
+// 4-7 during step 1, so one wave per SIMD always feeds the matrix pipe.  blockIdx is remapped so that
+// the column blocks sharing an A row block run on the same XCD.  240 workgroups for the 6400 x 1536
+// projections: one round on 256 CUs.  Measured (tools/bench_gemm.hip, random operands): 107 us at
+// K = 1024 (188 TF algorithmic) against 159 us for the first kernel; the kernel without any staging
+// runs 94 us and a pure-MFMA probe of the same instruction mix 69 us (1.75 PF executed).
+// ------------------------------------------------------------------------------------------
+constexpr int G3_BM = 160, G3_BN = 256, G3_BK = 32;
+constexpr int G3_APLANE = G3_BM * 64, G3_BPLANE = G3_BN * 64;
+constexpr int G3_BOFF = 3 * G3_APLANE;                      // 30,720
+constexpr int G3_STAGE = G3_BOFF + 3 * G3_BPLANE;           // 79,872
+constexpr int G3_LDS_BYTES = 2 * G3_STAGE;                  // 159,744
+constexpr int G3_APIECES = 3 * G3_BM / 16, G3_PIECES = G3_APIECES + 3 * G3_BN / 16;   // 30, 78
+typedef __attribute__((address_space(1))) const void* sir_gptr_t;
+typedef __attribute__((address_space(3))) void* sir_lptr_t;
+constexpr int G3_DEFAULT = 16;                              // product configuration of the KNOCK template word: SPREAD = 2
+
+// KNOCK: experiment word of tools/bench_gemm.hip.  bit 0 = no staging, bit 2 = no MFMAs (timing only), bits 3-4 = SPREAD,
+// bit 5 = PREF (see below)
+template <int KNOCK = G3_DEFAULT>
+static __global__ __launch_bounds__(512) void gemm_nt_bf16x6_v3_kernel(
+    const unsigned short* __restrict__ Ap, const unsigned short* __restrict__ Bp0, const unsigned short* __restrict__ Bp1,
+    const float* __restrict__ bias0, const float* __restrict__ bias1, float* __restrict__ C, int ldc, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char g3_smem[];
+    const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, rem = nwg & 7;
+    const int wgid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
+    const int nbd = N / G3_BN, nb = 2 * nbd;
+    const int mblk = wgid / nb, nbk = wgid - mblk * nb, z = nbk / nbd;
+    const int m0 = mblk * G3_BM, n0 = (nbk - z * nbd) * G3_BN;
+    const unsigned short* __restrict__ Bp = z ? Bp1 : Bp0;
+    const float* __restrict__ bias = z ? bias1 : bias0;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 31, h = lane >> 5;
+    const size_t planeA = (size_t)M * K, planeB = (size_t)N * K;
+
+    // LDS-DMA pieces of this wave: g = wv + 8 i (i < 10, g < 78); pieces 0..29 = A (plane g / 10, rows 16 (g % 10)..),
+    // 30..77 = B (plane (g - 30) / 16, rows 16 ((g - 30) % 16)..)
+    const int lr = lane >> 2;
+    const int csrc = (lane & 3) ^ ((lr >> 2) & 3);
+    unsigned int poff[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const int g = wv + 8 * i;
+        if (g < G3_APIECES) {
+            const int pl = g / 10, rg = g - pl * 10;
+            int row = m0 + rg * 16 + lr;
+            row = row < M ? row : M - 1;
+            poff[i] = (unsigned int)(pl * planeA + (size_t)row * K + csrc * 8);
+        } else {
+            const int gb = g - G3_APIECES, pl = gb >> 4, rg = gb & 15;
+            poff[i] = (unsigned int)(pl * planeB + (size_t)(n0 + rg * 16 + lr) * K + csrc * 8);
+        }
+    }
+    auto piece = [&](int i, int kt, int buf) {
+        if (KNOCK & 1) return;
+        const int g = wv + 8 * i;
+        if (g < G3_PIECES) {
+            const unsigned short* src = (g < G3_APIECES ? Ap : Bp) + poff[i] + (size_t)kt * G3_BK;
+            __builtin_amdgcn_global_load_lds((sir_gptr_t)src, (sir_lptr_t)(g3_smem + buf * G3_STAGE + g * 1024), 16, 0, 0);
+        }
+    };
+    auto stage = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) piece(i, kt, buf);
+    };
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+
+    int fo[2];                                              // byte offset of this lane's chunk inside its row, per MFMA step
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) fo[ks] = m * 64 + ((((ks << 1) | h) ^ ((m >> 2) & 3)) << 4);
+
+    // SPREAD (KNOCK bits 3-4): 0 = the next tile's DMA pieces are issued in bulk before the MFMAs, 1 = one piece after
+    // every third MFMA of step 0, 2 = waves 0-3 spread over step 0 and waves 4-7 (their SIMD partners) over step 1.
+    // PREF (bit 5): both steps' fragments are read before the first MFMA (pinned with sched_barrier).
+    constexpr int SPREAD = (KNOCK >> 3) & 3;
+    constexpr bool PREF = (KNOCK >> 5) & 1;
+    const int nk = K / G3_BK;
+    bf16x8 a[2][3][5], bb[2][3];
+    auto read_frags = [&](int buf, int ks) {
+        const unsigned char* abase = g3_smem + buf * G3_STAGE;
+        const unsigned char* bbase = abase + G3_BOFF + wv * 2048;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            bb[ks][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bbase + p * G3_BPLANE + fo[ks]));
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt)
+                a[ks][p][mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(abase + p * G3_APLANE + mt * 2048 + fo[ks]));
+        }
+    };
+    auto compute = [&](int buf, int ktn) {
+        // past the last tile the pieces re-load the last tile into the idle buffer (keeps the loop branch-free)
+        const int ktl = ktn < nk ? ktn : nk - 1;
+        read_frags(buf, 0);
+        if (PREF) {
+            read_frags(buf, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (!PREF && ks == 1) read_frags(buf, 1);
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt) {
+                    if (KNOCK & 4) acc[mt][0] += __builtin_bit_cast(float4, a[ks][PA[t]][mt]).x * __builtin_bit_cast(float4, bb[ks][PB[t]]).x;
+                    else acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][PA[t]][mt], bb[ks][PB[t]], acc[mt], 0, 0, 0);
+                    const int idx = t * 5 + mt;
+                    if (SPREAD && idx % 3 == 2) {
+                        if (SPREAD == 1 && ks == 0) piece(idx / 3, ktl, buf ^ 1);
+                        if (SPREAD == 2 && ks == (wv >> 2)) piece(idx / 3, ktl, buf ^ 1);
+                    }
+                }
+        }
+    };
+
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                                    // vmcnt(0) + barrier: tile kt landed, the other buffer is free
+        if (SPREAD == 0 && kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        compute(kt & 1, kt + 1);
+    }
+
+    const int n = n0 + wv * 32 + m;
+    const float bv = bias ? bias[n] : 0.0f;
+    float* crow = C + (size_t)(m0 + 4 * h) * ldc + (size_t)z * N + n;
+    if (m0 + G3_BM <= M) {                                  // whole tile in range: straight-line stores
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) crow[(size_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc] = acc[mt][r] + bv;
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = mt * 32 + (r & 3) + 8 * (r >> 2);
+                if (m0 + 4 * h + ro < M) crow[(size_t)ro * ldc] = acc[mt][r] + bv;
+            }
+    }
+}
+
+// host side of the two GEMM generations: the second needs N % 256 == 0, K % 32 == 0 and 32-bit plane offsets
+static inline bool gemm_bf16x6_v3_ok(int M, int N, int K) {
+    return N % G3_BN == 0 && K % G3_BK == 0 && (size_t)3 * M * K < ((size_t)1 << 31) && (size_t)3 * N * K < ((size_t)1 << 31);
+}
+static inline hipError_t launch_gemm_nt_bf16x6(hipStream_t st, int variant, const unsigned short* Ap, const unsigned short* Bp0,
+                                               const unsigned short* Bp1, const float* bias0, const float* bias1, float* C, int ldc,
+                                               int M, int N, int K) {
+    if (variant >= 2 && gemm_bf16x6_v3_ok(M, N, K)) {
+        static bool attr3 = false;
+        if (!attr3) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16x6_v3_kernel<G3_DEFAULT>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES);
+            if (e != hipSuccess) return e;
+            attr3 = true;
+        }
+        const int nwg = ((M + G3_BM - 1) / G3_BM) * 2 * (N / G3_BN);
+        hipLaunchKernelGGL(gemm_nt_bf16x6_v3_kernel<G3_DEFAULT>, dim3(nwg), dim3(512), G3_LDS_BYTES, st, Ap, Bp0, Bp1, bias0, bias1, C, ldc, M, N, K);
+    } else {
+        const dim3 grid((N + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M, 2);
+        hipLaunchKernelGGL(gemm_nt_bf16x6_kernel, grid, dim3(256), 0, st, Ap, Bp0, Bp1, bias0, bias1, C, ldc, M, N, K);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // conv 3x3 + BN + ReLU + 2x2 max-pool as an implicit GEMM on the bf16 matrix cores with the
 // bf16x6 split (same tiling idea as conv3x3_mfma_kernel: M = pixels in 8x4 patches, N = cout,
 // K = (tap, ci); pooling in registers).  The fp32 input tile is split into three bf16 planes while

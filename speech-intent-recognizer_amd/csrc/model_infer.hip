@@ -89,6 +89,11 @@ extern "C" int sir_model_workspace_offsets(const sir_handle* h, int batch, int t
 
 #define SIR_KCHECK() SIR_HIP_TRY(hipGetLastError())
 
+int sir_gemm_bf16x6_gen() {
+    static const int gen = getenv("SIR_GEMM_BF16X6_GEN") ? atoi(getenv("SIR_GEMM_BF16X6_GEN")) : 2;
+    return gen;
+}
+
 extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const float* feats, int batch, int t_frames,
                                float* logits, int64_t* argmax, void* workspace, size_t workspace_bytes, void* stream_) {
     if (!h || !w || !feats || !logits || !workspace) { sir_set_error("sir_model_infer: NULL argument"); return SIR_EINVAL; }
@@ -224,8 +229,8 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     { SirProfScope prof(h, SIR_K_GEMM_IH0, st);
     if (gemm_variant == 2) {
         hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, (const float*)x0, 1024, xs, (size_t)M, 1024);
-        hipLaunchKernelGGL(gemm_nt_bf16x6_kernel, ggrid, dim3(256), 0, st, (const unsigned short*)xs, (const unsigned short*)wsl0,
-                           (const unsigned short*)(wsl0 + (size_t)3 * 768 * 1024), w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024);
+        SIR_HIP_TRY(launch_gemm_nt_bf16x6(st, sir_gemm_bf16x6_gen(), (const unsigned short*)xs, (const unsigned short*)wsl0,
+                           (const unsigned short*)(wsl0 + (size_t)3 * 768 * 1024), w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024));
     } else if (gemm_variant == 1)
     hipLaunchKernelGGL((gemm_nt_bias_kernel<32, true>), ggrid, dim3(256), 0, st, x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
                        w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024);
@@ -242,8 +247,8 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     { SirProfScope prof(h, SIR_K_GEMM_IH1, st);
     if (gemm_variant == 2) {
         hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, (const float*)y0, 512, xs, (size_t)M, 512);
-        hipLaunchKernelGGL(gemm_nt_bf16x6_kernel, ggrid, dim3(256), 0, st, (const unsigned short*)xs, (const unsigned short*)wsl1,
-                           (const unsigned short*)(wsl1 + (size_t)3 * 768 * 512), w->gru_b_ih[2], w->gru_b_ih[3], gi, 1536, M, 768, 512);
+        SIR_HIP_TRY(launch_gemm_nt_bf16x6(st, sir_gemm_bf16x6_gen(), (const unsigned short*)xs, (const unsigned short*)wsl1,
+                           (const unsigned short*)(wsl1 + (size_t)3 * 768 * 512), w->gru_b_ih[2], w->gru_b_ih[3], gi, 1536, M, 768, 512));
     } else
     hipLaunchKernelGGL((gemm_nt_bias_kernel<32, true>), ggrid, dim3(256), 0, st, y0, 512, w->gru_w_ih[2], w->gru_w_ih[3], 512,
                        w->gru_b_ih[2], w->gru_b_ih[3], gi, 1536, M, 768, 512); }

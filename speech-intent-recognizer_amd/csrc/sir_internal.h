@@ -88,3 +88,6 @@ int sir_features_launch(sir_handle* h, const void* wave, int wave_dtype, int64_t
                         const int32_t* lengths, int batch, int max_len, float* out, int t_pad,
                         float* db_out, void* workspace, size_t workspace_bytes, const sir_augment* aug,
                         hipStream_t stream);
+
+// generation of the bf16x6 input-projection GEMM (SIR_GEMM_BF16X6_GEN, default 2 = LDS-DMA kernel; 1 = first kernel)
+int sir_gemm_bf16x6_gen();
