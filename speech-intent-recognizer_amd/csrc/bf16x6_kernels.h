@@ -12,19 +12,32 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned short bf16_rne(float x) {
-    unsigned int u = __float_as_uint(x);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf16_as_f32(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+typedef __bf16 sir_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float sir_f32x2 __attribute__((ext_vector_type(2)));
 
+// exact three-way split of two floats at once; packed results (a in the low half).  The conversions
+// compile to v_cvt_pk_bf16_f32 (round to nearest even) and the residuals to v_pk_add_f32: 9 VALU
+// instructions per pair.
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    sir_f32x2 v = {a, b};
+    const sir_bf16x2 hi = __builtin_convertvector(v, sir_bf16x2);
+    v -= __builtin_convertvector(hi, sir_f32x2);            // exact
+    const sir_bf16x2 mid = __builtin_convertvector(v, sir_bf16x2);
+    v -= __builtin_convertvector(mid, sir_f32x2);           // exact
+    const sir_bf16x2 lo = __builtin_convertvector(v, sir_bf16x2);
+    h = __builtin_bit_cast(unsigned, hi);
+    m = __builtin_bit_cast(unsigned, mid);
+    l = __builtin_bit_cast(unsigned, lo);
+}
 __device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
-    h = bf16_rne(x);
-    const float r1 = x - bf16_as_f32(h);          // exact
-    m = bf16_rne(r1);
-    const float r2 = r1 - bf16_as_f32(m);         // exact
-    l = bf16_rne(r2);
+    unsigned ph, pm, pl;
+    split3_pair(x, 0.0f, ph, pm, pl);
+    h = (unsigned short)ph; m = (unsigned short)pm; l = (unsigned short)pl;
+}
+// float4 -> one 8-byte group per plane
+__device__ __forceinline__ void split3_quad(const float4& v, uint2& h, uint2& m, uint2& l) {
+    split3_pair(v.x, v.y, h.x, m.x, l.x);
+    split3_pair(v.z, v.w, h.y, m.y, l.y);
 }
 
 // in [rows][K] fp32 (row stride ld_in) -> planes [3][rows][K] bf16; one thread = 8 consecutive k
@@ -37,18 +50,13 @@ static __global__ __launch_bounds__(256) void split3_kernel(const float* __restr
         const int k8 = idx % k8n;
         const float4 v0 = *reinterpret_cast<const float4*>(in + row * ld_in + k8 * 8);
         const float4 v1 = *reinterpret_cast<const float4*>(in + row * ld_in + k8 * 8 + 4);
-        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        unsigned short h[8], m[8], l[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) split3(x[i], h[i], m[i], l[i]);
-        auto pack = [](const unsigned short* p) {
-            return make_uint4(p[0] | ((unsigned)p[1] << 16), p[2] | ((unsigned)p[3] << 16), p[4] | ((unsigned)p[5] << 16),
-                              p[6] | ((unsigned)p[7] << 16));
-        };
+        uint2 h0, m0, l0, h1, m1, l1;
+        split3_quad(v0, h0, m0, l0);
+        split3_quad(v1, h1, m1, l1);
         const size_t o = row * K + (size_t)k8 * 8;
-        *reinterpret_cast<uint4*>(out + o) = pack(h);
-        *reinterpret_cast<uint4*>(out + plane + o) = pack(m);
-        *reinterpret_cast<uint4*>(out + 2 * plane + o) = pack(l);
+        *reinterpret_cast<uint4*>(out + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        *reinterpret_cast<uint4*>(out + plane + o) = make_uint4(m0.x, m0.y, m1.x, m1.y);
+        *reinterpret_cast<uint4*>(out + 2 * plane + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
 }
 
@@ -410,13 +418,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gy >= 0 && gy < H && gx >= 0 && gx < W)
                 v = *reinterpret_cast<const float4*>(xb + ((size_t)gy * W + gx) * CIN + cc * CK + part * 4);
-            unsigned short hh[4], mm[4], ll[4];
-            split3(v.x, hh[0], mm[0], ll[0]); split3(v.y, hh[1], mm[1], ll[1]);
-            split3(v.z, hh[2], mm[2], ll[2]); split3(v.w, hh[3], mm[3], ll[3]);
+            uint2 hh, mm, ll;
+            split3_quad(v, hh, mm, ll);
             unsigned char* d = ldsb + pix * PSB + part * 8;
-            *reinterpret_cast<uint2*>(d) = make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
-            *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(mm[0] | ((unsigned)mm[1] << 16), mm[2] | ((unsigned)mm[3] << 16));
-            *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
+            *reinterpret_cast<uint2*>(d) = hh;
+            *reinterpret_cast<uint2*>(d + PLANE) = mm;
+            *reinterpret_cast<uint2*>(d + 2 * PLANE) = ll;
         }
         __syncthreads();
         if (!wvalid) continue;
@@ -525,6 +532,178 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(
                     for (int q = 0; q < 4; ++q)
                         if (PYb + q < Hp) o[q] = pooled[q];
                 }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Second generation of the bf16x6 convolution: output channels split ACROSS the waves.
+//   conv3x3_bf16x6_kernel gives every wave all COUT channels of its own pixel patches, so the four
+//   waves of a workgroup each stream the full weight set of a tap from L2 (12 KiB per wave and tap
+//   for 64 -> 128 channels: ~1.8 GB of L2 reads per launch at batch 256).  Here a wave owns ONE
+//   32-channel slice (wn = wave % WN, WN = COUT / 32) and MT = PR * PC / (4 / WN) pixel patches: its
+//   weight fragments are private (3 x 16 B per lane and tap, prefetched one tap ahead) and the pixel
+//   fragments, which every wave needs, come from the shared LDS tile.  Same tile, LDS image, MFMA
+//   order per accumulator and epilogues as the first kernel: results are bit-identical.
+//   KNOCK (tools/bench_conv.hip timing experiments; 0 in the product): bit 0 = weights loaded once,
+//   bit 1 = input tile staged once.
+// ------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int PR, int PC, int OUT_MODE, int KNOCK = 0>
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_ns_kernel(
+    const float* __restrict__ x, const unsigned short* __restrict__ wpb, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp, float2* __restrict__ stats) {
+    constexpr int WN = COUT / 32, WM = 4 / WN, MT = PR * PC / WM, CK = 16, PSB = 48;
+    constexpr int GS = MT < 4 ? MT : 4;                     // patches per MFMA group (independent accumulators in flight)
+    constexpr int TR = 8 * PR, TC = 4 * PC, TROWS = TR + 2, TCOLS = TC + 2;
+    constexpr int PLANE = TROWS * TCOLS * PSB;
+    constexpr int G = (CIN / 16) * 9;
+    static_assert(COUT % 32 == 0 && WN <= 4 && 4 % WN == 0 && (PR * PC) % WM == 0 && MT % GS == 0 && CIN % CK == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    const int b = blockIdx.z, ty0 = blockIdx.y * TR, tx0 = blockIdx.x * TC;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wn = wv % WN, wm = wv / WN;
+    const int m = lane & 31, h = lane >> 5;
+    const int pxl = (m & 1) + 2 * ((m >> 2) & 1);
+    const int pyl = ((m >> 1) & 1) + 2 * ((m >> 3) & 1) + 4 * ((m >> 4) & 1);
+    // patch pi = wm * MT + mt: row block pi % PR, column block pi / PR (column blocks ascend with mt)
+    const int lane_off = (pyl * TCOLS + pxl) * PSB + h * 16;
+    int nvalid = 0;                                         // patches of this wave that start inside the image (a prefix)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) nvalid += (tx0 + 4 * ((wm * MT + mt) / PR) < W) ? 1 : 0;
+    nvalid = __builtin_amdgcn_readfirstlane(nvalid);
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+    const uint4* wp4 = reinterpret_cast<const uint4*>(wpb) + (size_t)(wn * 32 + m) * 2 + h;   // + ((p*G + g)*COUT)*2
+    const float* xb = x + (size_t)b * H * W * CIN;
+    auto load_w = [&](int g, uint4 (&wf)[3]) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wf[p] = wp4[((size_t)p * G + g) * COUT * 2];
+    };
+
+    uint4 wcur[3], wnext[3];
+    load_w(0, wcur);
+    for (int cc = 0; cc < CIN / CK; ++cc) {
+        if (!(KNOCK & 2) || cc == 0) {
+        if (cc) __syncthreads();
+        for (int idx = tid; idx < TROWS * TCOLS * 4; idx += 256) {
+            const int pix = idx >> 2, part = idx & 3;
+            const int tyy = pix / TCOLS, txx = pix - tyy * TCOLS;
+            const int gy = ty0 - 1 + tyy, gx = tx0 - 1 + txx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4*>(xb + ((size_t)gy * W + gx) * CIN + cc * CK + part * 4);
+            uint2 hh, mm, ll;
+            split3_quad(v, hh, mm, ll);
+            unsigned char* d = ldsb + pix * PSB + part * 8;
+            *reinterpret_cast<uint2*>(d) = hh;
+            *reinterpret_cast<uint2*>(d + PLANE) = mm;
+            *reinterpret_cast<uint2*>(d + 2 * PLANE) = ll;
+        }
+        __syncthreads();
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3, g = cc * 9 + tap;
+            if (!(KNOCK & 1) && g + 1 < G) load_w(g + 1, wnext);
+            bf16x8 bfr[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bfr[p] = __builtin_bit_cast(bf16x8, wcur[p]);
+            const unsigned char* tapbase = ldsb + lane_off + (ky * TCOLS + kx) * PSB;
+#pragma unroll
+            for (int g0 = 0; g0 < MT; g0 += GS) {
+                if (g0 >= nvalid) break;
+                bf16x8 afr[GS][3];
+#pragma unroll
+                for (int i = 0; i < GS; ++i) {
+                    const int pi = wm * MT + g0 + i, poff = ((8 * (pi % PR)) * TCOLS + 4 * (pi / PR)) * PSB;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        afr[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tapbase + p * PLANE + poff));
+                }
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < GS; ++i)
+                        acc[g0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][PA[t]], bfr[PB[t]], acc[g0 + i], 0, 0, 0);
+            }
+            if (!(KNOCK & 1) && g + 1 < G) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wcur[p] = wnext[p];
+            }
+        }
+    }
+    const int co = wn * 32 + m;
+    if (OUT_MODE == 2) {
+        // raw epilogue (training forward / data gradient) + per-workgroup channel statistics
+        float ssum = 0.0f, ssq = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int pi = wm * MT + mt, pr = pi % PR, pc = pi / PR;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int xl = (r & 1) + 2 * h, yl = ((r >> 1) & 1) + 2 * ((r >> 2) & 1) + 4 * ((r >> 3) & 1);
+                const int gy = ty0 + 8 * pr + yl, gx = tx0 + 4 * pc + xl;
+                if (gy < H && gx < W) {
+                    const float v = acc[mt][r];
+                    out[(((size_t)b * H + gy) * W + gx) * COUT + co] = v;
+                    ssum += v;
+                    ssq = fmaf(v, v, ssq);
+                }
+            }
+        }
+        if (stats) {
+            float* lds = reinterpret_cast<float*>(ldsb);
+            ssum += __shfl_xor(ssum, 32);
+            ssq += __shfl_xor(ssq, 32);
+            __syncthreads();
+            if (h == 0) {
+                lds[(wm * COUT + co) * 2] = ssum;
+                lds[(wm * COUT + co) * 2 + 1] = ssq;
+            }
+            __syncthreads();
+            const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            for (int c = tid; c < COUT; c += 256) {
+                float s = 0.0f, q = 0.0f;
+#pragma unroll
+                for (int w4 = 0; w4 < WM; ++w4) { s += lds[(w4 * COUT + c) * 2]; q += lds[(w4 * COUT + c) * 2 + 1]; }
+                stats[blk * COUT + c] = make_float2(s, q);
+            }
+        }
+        return;
+    }
+    // epilogue: BN (folded) -> ReLU -> 2x2 max over registers 4q..4q+3 -> store
+    const float s = scale[co], t = shift[co];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int pi = wm * MT + mt, pr = pi % PR, pc = pi / PR;
+        const int PX = (tx0 + 4 * pc) / 2 + h;
+        const int PYb = (ty0 + 8 * pr) / 2;
+        if (PX >= Wp) continue;
+        float pooled[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v = fmaxf(v, fmaf(acc[mt][4 * q + r], s, t));
+            pooled[q] = v;
+        }
+        if (OUT_MODE == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (PYb + q < Hp) out[(((size_t)b * Hp + PYb + q) * Wp + PX) * COUT + co] = pooled[q];
+        } else {
+            float* o = out + ((size_t)b * Wp + PX) * (COUT * Hp) + (size_t)co * Hp + PYb;
+            if ((Hp & 3) == 0) {
+                *reinterpret_cast<float4*>(o) = make_float4(pooled[0], pooled[1], pooled[2], pooled[3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (PYb + q < Hp) o[q] = pooled[q];
             }
         }
     }

@@ -89,6 +89,11 @@ extern "C" int sir_model_workspace_offsets(const sir_handle* h, int batch, int t
 
 #define SIR_KCHECK() SIR_HIP_TRY(hipGetLastError())
 
+int sir_conv_ns() {
+    static const int v = getenv("SIR_CONV_NS") ? atoi(getenv("SIR_CONV_NS")) : 1;
+    return v;
+}
+
 int sir_gemm_bf16x6_gen() {
     static const int gen = getenv("SIR_GEMM_BF16X6_GEN") ? atoi(getenv("SIR_GEMM_BF16X6_GEN")) : 2;
     return gen;
@@ -178,6 +183,10 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
         SirProfScope prof(h, SIR_K_CONV2, st);
         if (conv_bf16) {
             constexpr size_t lds = (size_t)3 * (8 * 4 + 2) * (4 * 2 + 2) * 48;
+            if (sir_conv_ns())
+            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 0>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), lds, st, a1,
+                               (const unsigned short*)wcb2, bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
+            else
             hipLaunchKernelGGL((conv3x3_bf16x6_kernel<32, 64, 4, 2, 0, 2>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), lds, st, a1,
                                (const unsigned short*)wcb2, bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
         } else if (conv2_variant == 0) {
@@ -199,6 +208,10 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
         static const int conv3_variant = getenv("SIR_CONV3_VARIANT") ? atoi(getenv("SIR_CONV3_VARIANT")) : 0;
         if (conv_bf16 && conv3_variant == 0) {
         constexpr size_t lds = (size_t)3 * (8 * 2 + 2) * (4 * 4 + 2) * 48;
+        if (sir_conv_ns())
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 4, 1>), dim3((d.wp2 + 15) / 16, 1, B), dim3(256), lds, st, a2,
+                           (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)nullptr);
+        else
         hipLaunchKernelGGL((conv3x3_bf16x6_kernel<64, 128, 2, 4, 1, 2>), dim3((d.wp2 + 15) / 16, 1, B), dim3(256), lds, st, a2,
                            (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)nullptr);
         } else if (conv_bf16) {

@@ -91,3 +91,5 @@ int sir_features_launch(sir_handle* h, const void* wave, int wave_dtype, int64_t
 
 // generation of the bf16x6 input-projection GEMM (SIR_GEMM_BF16X6_GEN, default 2 = LDS-DMA kernel; 1 = first kernel)
 int sir_gemm_bf16x6_gen();
+// convolution generation (SIR_CONV_NS, default 1 = output channels split over the waves)
+int sir_conv_ns();
