@@ -347,6 +347,17 @@ static inline hipError_t launch_gemm_nt_bf16x6(hipStream_t st, int variant, cons
 // it is staged into LDS (16 input channels per chunk, 48-byte pixel rows); the weights arrive
 // pre-split from prep_conv_w_bf16x3_kernel as wpb[plane][g = ci/16*9 + tap][co][16].
 // ------------------------------------------------------------------------------------------
+// LDS image of the convolution input tile: 48-byte pixels (16 channels x 3 planes kept in separate plane
+// blocks), rows padded to a stride of 4 (mod 8) sixteen-byte slots.  ds_read_b128 serves the lanes in the
+// groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with the 8x4 patch bit layout of a fragment those 16
+// lanes then hit 16 different slots of the 256-byte bank line (the natural strides 30 and 54 give 2-way
+// conflicts on two lane pairs per group: SQ_LDS_BANK_CONFLICT = 50 % of LDS cycles).
+constexpr int conv_bf16x6_row_bytes(int PC) {
+    const int slots = (4 * PC + 2) * 3;
+    return (slots + ((4 - slots % 8) + 8) % 8) * 16;
+}
+constexpr size_t conv_bf16x6_lds_bytes(int PR, int PC) { return (size_t)3 * (8 * PR + 2) * conv_bf16x6_row_bytes(PC); }
+
 static __global__ void prep_conv_w_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin, int cout) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = cin * 9 * cout;
@@ -381,7 +392,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(
     const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp, float2* __restrict__ stats) {
     constexpr int NT = COUT / 32, CK = 16, PSB = 48;
     constexpr int TR = 8 * PR, TC = 4 * PC, TROWS = TR + 2, TCOLS = TC + 2;
-    constexpr int PLANE = TROWS * TCOLS * PSB;              // bytes per plane
+    constexpr int RSB = conv_bf16x6_row_bytes(PC);          // padded row stride
+    constexpr int PLANE = TROWS * RSB;                      // bytes per plane
     constexpr int G = (CIN / 16) * 9;
     static_assert(PR * PC == 4 * MT && CIN % CK == 0 && (MT == 1 || PR % 2 == 0), "tile shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(
         const int pi = MT * wv + mt;
         pr_[mt] = pi % PR;
         pc_[mt] = pi / PR;
-        aoff[mt] = ((8 * pr_[mt] + pyl) * TCOLS + 4 * pc_[mt] + pxl) * PSB + h * 16;
+        aoff[mt] = (8 * pr_[mt] + pyl) * RSB + (4 * pc_[mt] + pxl) * PSB + h * 16;
     }
     const bool wvalid = __builtin_amdgcn_readfirstlane((tx0 + 4 * pc_[0] < W) ? 1 : 0) != 0;
     f32x16 acc[MT][NT];
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(
                 v = *reinterpret_cast<const float4*>(xb + ((size_t)gy * W + gx) * CIN + cc * CK + part * 4);
             uint2 hh, mm, ll;
             split3_quad(v, hh, mm, ll);
-            unsigned char* d = ldsb + pix * PSB + part * 8;
+            unsigned char* d = ldsb + tyy * RSB + txx * PSB + part * 8;
             *reinterpret_cast<uint2*>(d) = hh;
             *reinterpret_cast<uint2*>(d + PLANE) = mm;
             *reinterpret_cast<uint2*>(d + 2 * PLANE) = ll;
@@ -440,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
-                    afr[mt][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ldsb + p * PLANE + aoff[mt] + (ky * TCOLS + kx) * PSB));
+                    afr[mt][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ldsb + p * PLANE + aoff[mt] + ky * RSB + kx * PSB));
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -556,7 +568,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_ns_kernel(
     constexpr int WN = COUT / 32, WM = 4 / WN, MT = PR * PC / WM, CK = 16, PSB = 48;
     constexpr int GS = MT < 4 ? MT : 4;                     // patches per MFMA group (independent accumulators in flight)
     constexpr int TR = 8 * PR, TC = 4 * PC, TROWS = TR + 2, TCOLS = TC + 2;
-    constexpr int PLANE = TROWS * TCOLS * PSB;
+    constexpr int RSB = conv_bf16x6_row_bytes(PC);
+    constexpr int PLANE = TROWS * RSB;
     constexpr int G = (CIN / 16) * 9;
     static_assert(COUT % 32 == 0 && WN <= 4 && 4 % WN == 0 && (PR * PC) % WM == 0 && MT % GS == 0 && CIN % CK == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -567,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_ns_kernel(
     const int pxl = (m & 1) + 2 * ((m >> 2) & 1);
     const int pyl = ((m >> 1) & 1) + 2 * ((m >> 3) & 1) + 4 * ((m >> 4) & 1);
     // patch pi = wm * MT + mt: row block pi % PR, column block pi / PR (column blocks ascend with mt)
-    const int lane_off = (pyl * TCOLS + pxl) * PSB + h * 16;
+    const int lane_off = pyl * RSB + pxl * PSB + h * 16;
     int nvalid = 0;                                         // patches of this wave that start inside the image (a prefix)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) nvalid += (tx0 + 4 * ((wm * MT + mt) / PR) < W) ? 1 : 0;
@@ -598,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_ns_kernel(
                 v = *reinterpret_cast<const float4*>(xb + ((size_t)gy * W + gx) * CIN + cc * CK + part * 4);
             uint2 hh, mm, ll;
             split3_quad(v, hh, mm, ll);
-            unsigned char* d = ldsb + pix * PSB + part * 8;
+            unsigned char* d = ldsb + tyy * RSB + txx * PSB + part * 8;
             *reinterpret_cast<uint2*>(d) = hh;
             *reinterpret_cast<uint2*>(d + PLANE) = mm;
             *reinterpret_cast<uint2*>(d + 2 * PLANE) = ll;
@@ -612,14 +625,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_ns_kernel(
             bf16x8 bfr[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) bfr[p] = __builtin_bit_cast(bf16x8, wcur[p]);
-            const unsigned char* tapbase = ldsb + lane_off + (ky * TCOLS + kx) * PSB;
+            const unsigned char* tapbase = ldsb + lane_off + ky * RSB + kx * PSB;
 #pragma unroll
             for (int g0 = 0; g0 < MT; g0 += GS) {
                 if (g0 >= nvalid) break;
                 bf16x8 afr[GS][3];
 #pragma unroll
                 for (int i = 0; i < GS; ++i) {
-                    const int pi = wm * MT + g0 + i, poff = ((8 * (pi % PR)) * TCOLS + 4 * (pi / PR)) * PSB;
+                    const int pi = wm * MT + g0 + i, poff = 8 * (pi % PR) * RSB + 4 * (pi / PR) * PSB;
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
                         afr[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tapbase + p * PLANE + poff));

@@ -182,7 +182,7 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     {
         SirProfScope prof(h, SIR_K_CONV2, st);
         if (conv_bf16) {
-            constexpr size_t lds = (size_t)3 * (8 * 4 + 2) * (4 * 2 + 2) * 48;
+            constexpr size_t lds = conv_bf16x6_lds_bytes(4, 2);
             if (sir_conv_ns())
             hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 0>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), lds, st, a1,
                                (const unsigned short*)wcb2, bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
@@ -207,7 +207,7 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
         SirProfScope prof(h, SIR_K_CONV3, st);
         static const int conv3_variant = getenv("SIR_CONV3_VARIANT") ? atoi(getenv("SIR_CONV3_VARIANT")) : 0;
         if (conv_bf16 && conv3_variant == 0) {
-        constexpr size_t lds = (size_t)3 * (8 * 2 + 2) * (4 * 4 + 2) * 48;
+        constexpr size_t lds = conv_bf16x6_lds_bytes(2, 4);
         if (sir_conv_ns())
         hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 4, 1>), dim3((d.wp2 + 15) / 16, 1, B), dim3(256), lds, st, a2,
                            (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)nullptr);
@@ -215,7 +215,7 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
         hipLaunchKernelGGL((conv3x3_bf16x6_kernel<64, 128, 2, 4, 1, 2>), dim3((d.wp2 + 15) / 16, 1, B), dim3(256), lds, st, a2,
                            (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)nullptr);
         } else if (conv_bf16) {
-        constexpr size_t lds = (size_t)3 * (8 * 2 + 2) * (4 * 2 + 2) * 48;
+        constexpr size_t lds = conv_bf16x6_lds_bytes(2, 2);
         hipLaunchKernelGGL((conv3x3_bf16x6_kernel<64, 128, 2, 2, 1, 1>), dim3((d.wp2 + 7) / 8, 1, B), dim3(256), lds, st, a2,
                            (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)nullptr);
         } else if (conv3_variant == 0) {

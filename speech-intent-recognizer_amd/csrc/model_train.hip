@@ -216,7 +216,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     }
     // conv2 block: raw conv + partial statistics on MFMA, finalize, BN+ReLU+pool
     {
-        constexpr size_t lds = (size_t)3 * (8 * 4 + 2) * (4 * 2 + 2) * 48;
+        constexpr size_t lds = conv_bf16x6_lds_bytes(4, 2);
         if (sir_conv_ns())
         hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 2>), dim3(d.c2gx, 1, B), dim3(256), lds, st, (const float*)p.a1,
                            (const unsigned short*)p.wcb2, (const float*)nullptr, (const float*)nullptr, p.z2, 32, d.wp1, 16, d.wp2, p.stats);
@@ -230,7 +230,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
                            scale + 32, shift + 32, p.a2, B, 32, d.wp1, 64, 16, d.wp2);
     }
     {
-        constexpr size_t lds = (size_t)3 * (8 * 2 + 2) * (4 * 4 + 2) * 48;
+        constexpr size_t lds = conv_bf16x6_lds_bytes(2, 4);
         if (sir_conv_ns())
         hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 4, 2>), dim3(d.c3gx, 1, B), dim3(256), lds, st, (const float*)p.a2,
                            (const unsigned short*)p.wcb3, (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats);
@@ -383,7 +383,7 @@ extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, co
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 128 * 64 + 255) / 256), dim3(256), 0, st, (const float*)p.slab,
                            d.wg3_blocks, 64, 128, g->conv_w[2]);
         hipLaunchKernelGGL(prep_conv_wT_bf16x3_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], p.wcb3t, 64, 128);
-        constexpr size_t ldsd = (size_t)3 * (8 * 2 + 2) * (4 * 4 + 2) * 48;
+        constexpr size_t ldsd = conv_bf16x6_lds_bytes(2, 4);
         if (sir_conv_ns())
         hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<128, 64, 2, 4, 2>), dim3(d.c3gx, 1, B), dim3(256), ldsd, st, (const float*)p.dz3,
                            (const unsigned short*)p.wcb3t, (const float*)nullptr, (const float*)nullptr, p.da2, 16, d.wp2, 8, d.wp3,
@@ -419,7 +419,7 @@ extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, co
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 32 + 255) / 256), dim3(256), 0, st, (const float*)p.slab,
                            d.wg2_blocks, 32, 64, g->conv_w[1]);
         hipLaunchKernelGGL(prep_conv_wT_bf16x3_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], p.wcb2t, 32, 64);
-        constexpr size_t ldsd = (size_t)3 * (8 * 4 + 2) * (4 * 2 + 2) * 48;
+        constexpr size_t ldsd = conv_bf16x6_lds_bytes(4, 2);
         if (sir_conv_ns())
         hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 32, 4, 2, 2>), dim3(d.c2gx, 1, B), dim3(256), ldsd, st, (const float*)p.dz2,
                            (const unsigned short*)p.wcb2t, (const float*)nullptr, (const float*)nullptr, p.da1, 32, d.wp1, 16, d.wp2,

@@ -44,7 +44,7 @@ static void run(const char* name, int B, int H, int W) {
     CK_(hipMemcpy(ds, hs.data(), COUT * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(dt, ht.data(), COUT * 4, hipMemcpyHostToDevice));
     hipStream_t st; CK_(hipStreamCreate(&st));
     hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((CIN * 9 * COUT + 255) / 256), dim3(256), 0, st, (const float*)dw, wpb, CIN, COUT);
-    constexpr size_t lds = (size_t)3 * (8 * PR + 2) * (4 * PC + 2) * 48;
+    constexpr size_t lds = conv_bf16x6_lds_bytes(PR, PC);
     const dim3 grid((W + 4 * PC - 1) / (4 * PC), (H + 8 * PR - 1) / (8 * PR), B);
     const double gf = 2.0 * B * H * W * (double)COUT * CIN * 9 * 1e-9;
     CK_(hipMemset(o1, 0, nout * 4)); CK_(hipMemset(o2, 0, nout * 4));
