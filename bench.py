@@ -154,6 +154,43 @@ def cpu_baseline(target_seconds=12.0):
             "single_thread_value": round(one_rate, 2)}, pred
 
 
+def cpu_train_baseline(cores, target_seconds=8.0):
+    """Reference CPU training step restated (train.py:90-107 on stock torch.nn layers, oracle.TrainRef):
+    zero_grad, forward, CE, backward, Adam(lr 5e-5, wd 1e-4) on cached features [batch, 64, 200]."""
+    from oracle import model_ref
+    from sir_amd import synth
+    torch.set_num_threads(cores)
+    out = {}
+    for batch in (8, 256):
+        m = model_ref.TrainRef(synth.synth_state_dict(NUM_CLASSES, seed=0), NUM_CLASSES).train()
+        opt = torch.optim.Adam(m.parameters(), lr=5e-5, weight_decay=1e-4)
+        x = synth.synth_features(batch, 200, seed=7)
+        y = synth.synth_labels(batch, NUM_CLASSES, seed=5)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.cross_entropy(m(x), y)
+            loss.backward()
+            opt.step()
+            return loss.item()
+
+        step()
+        t0 = time.perf_counter()
+        step()
+        dt = time.perf_counter() - t0
+        reps = max(1, min(30, int(target_seconds / 2 / max(dt, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        out[batch] = (batch * reps / (time.perf_counter() - t0), reps)
+        log(f"cpu_train_baseline: batch {batch}: {out[batch][0]:.1f} utt/s ({reps} steps, {cores} threads)")
+    best = max(out[8][0], out[256][0])                      # the faster CPU configuration is the baseline
+    return {"value": round(best, 2), "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": f"{out[256][1]} training steps at batch 256 and {out[8][1]} at batch 8 on cached features (value = the "
+                      "faster of the two): stock torch.nn layers + CE + backward + Adam, oracle/ restatement of train.py:90-107",
+            "batch8_value": round(out[8][0], 2), "batch256_value": round(out[256][0], 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,6 +379,10 @@ def main():
             out["speedup_vs_cpu_all_cores"] = round(value / base["value"], 1)
             # parity flag on the very sample the CPU baseline ran: predicted indices identical
             out["parity"] = {"argmax_identical_on_cpu_sample": bool(torch.equal(gpu_pred32, cpu_pred))}
+            if train_info is not None:
+                tb = cpu_train_baseline(base["cores"])
+                out["train"]["cpu_baseline"] = tb
+                out["train"]["speedup_vs_cpu_all_cores"] = round(train_info["value"] / tb["value"], 1)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

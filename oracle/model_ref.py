@@ -187,3 +187,32 @@ class FastRef:
         y, _ = self.gru(x.permute(0, 3, 1, 2).reshape(b, w, c * h))
         attn = torch.softmax(F.linear(y, sd["attention.weight"], sd["attention.bias"]), dim=1)
         return F.linear((y * attn).sum(dim=1), sd["fc.weight"], sd["fc.bias"])
+
+
+class TrainRef(torch.nn.Module):
+    """Stock torch.nn layers under the reference's parameter names (models.py:6-39 restated: three
+    conv/BN/ReLU/pool blocks, 2-layer bidirectional GRU with inter-layer dropout 0.5, attention pooling,
+    linear head) -- what the reference's ``train_epoch`` differentiates on CPU.  Used ONLY to time the CPU
+    training baseline in bench.py; the parity checks use ``loss_and_grads`` above."""
+
+    def __init__(self, sd, num_classes):
+        super().__init__()
+        nn = torch.nn
+        self.conv1 = nn.Conv2d(1, 32, 3, padding=1, bias=False)
+        self.conv2 = nn.Conv2d(32, 64, 3, padding=1, bias=False)
+        self.conv3 = nn.Conv2d(64, 128, 3, padding=1, bias=False)
+        self.bn1, self.bn2, self.bn3 = nn.BatchNorm2d(32), nn.BatchNorm2d(64), nn.BatchNorm2d(128)
+        self.gru = nn.GRU(1024, HIDDEN, num_layers=2, batch_first=True, bidirectional=True, dropout=0.5)
+        self.attention = nn.Linear(2 * HIDDEN, 1)
+        self.fc = nn.Linear(2 * HIDDEN, num_classes)
+        self.load_state_dict({k: v for k, v in sd.items()}, strict=True)
+
+    def forward(self, x):
+        if x.dim() == 3:
+            x = x.unsqueeze(1)
+        for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)):
+            x = F.max_pool2d(F.relu(bn(conv(x))), 2)
+        b, c, h, w = x.shape
+        y, _ = self.gru(x.permute(0, 3, 1, 2).reshape(b, w, c * h))
+        attn = torch.softmax(self.attention(y), dim=1)
+        return self.fc((y * attn).sum(dim=1))

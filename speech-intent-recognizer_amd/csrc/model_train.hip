@@ -92,7 +92,7 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     const size_t s_w2 = (size_t)d.wg2_blocks * 9 * 64 * 32, s_g = (size_t)d.ksplits * 768 * 1024;
     if (s_w2 > slab) slab = s_w2;
     if (s_g > slab) slab = s_g;
-    n[TB_SLAB] = slab;
+    n[TB_SLAB] = slab + (size_t)WGR_PARTS * 9 * 128 * 64;       // + the partial sums of the two-pass wgrad reduce
     n[TB_XS] = (B * S * 1024 * 3 + 1) / 2;                       // ushort count / 2 (sizes are in floats)
     n[TB_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512 + 1) / 2;
     n[TB_WCB] = ((size_t)2 * (3 * 32 * 9 * 64 + 3 * 64 * 9 * 128) + 1) / 2;
@@ -318,7 +318,7 @@ extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, co
     const dim3 rgrid((B + GRU_BW - 1) / GRU_BW, 2);
 
     // ---- head: fc + attention pooling ----------------------------------------------------
-    hipLaunchKernelGGL(fc_wgrad_kernel, dim3(C), dim3(256), 0, st, dlogits, (const float*)p.ctx, g->fc_w, g->fc_b, B, C);
+    hipLaunchKernelGGL(fc_wgrad_kernel, dim3(C, 2), dim3(256), 0, st, dlogits, (const float*)p.ctx, g->fc_w, g->fc_b, B, C);
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, st, dlogits, w->fc_w, (const float*)p.y1, w->attn_w, w->attn_b,
                        p.dy1, daw_part, dab_part, S, C);
     hipLaunchKernelGGL(colsum_kernel, dim3(8), dim3(256), 0, st, (const float*)daw_part, B, 512, 512, g->attn_w);
@@ -380,8 +380,13 @@ extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, co
         if (lds > 160 * 1024) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
         hipLaunchKernelGGL((conv_wgrad_mfma_kernel<64, 128>), dim3(d.wg3_blocks), dim3(576), lds, st, (const float*)p.dz3,
                            (const float*)p.a2, p.slab, 16, d.wp2, d.wg3_rb);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 128 * 64 + 255) / 256), dim3(256), 0, st, (const float*)p.slab,
-                           d.wg3_blocks, 64, 128, g->conv_w[2]);
+{
+            float* part = p.slab + (size_t)d.wg3_blocks * 9 * 128 * 64;
+            hipLaunchKernelGGL(wgrad_reduce_partial_kernel, dim3((9 * 128 * 64 / 4 + 255) / 256, WGR_PARTS), dim3(256), 0, st,
+                               (const float*)p.slab, d.wg3_blocks, 9 * 128 * 64 / 4, part);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 128 * 64 + 255) / 256), dim3(256), 0, st, (const float*)part, WGR_PARTS, 64, 128,
+                               g->conv_w[2]);
+        }
         hipLaunchKernelGGL(prep_conv_wT_bf16x3_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], p.wcb3t, 64, 128);
         constexpr size_t ldsd = conv_bf16x6_lds_bytes(2, 4);
         if (sir_conv_ns())
@@ -416,8 +421,13 @@ extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, co
         if (lds > 160 * 1024) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
         hipLaunchKernelGGL((conv_wgrad_mfma_kernel<32, 64>), dim3(d.wg2_blocks), dim3(576), lds, st, (const float*)p.dz2,
                            (const float*)p.a1, p.slab, 32, d.wp1, d.wg2_rb);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 32 + 255) / 256), dim3(256), 0, st, (const float*)p.slab,
-                           d.wg2_blocks, 32, 64, g->conv_w[1]);
+{
+            float* part = p.slab + (size_t)d.wg2_blocks * 9 * 64 * 32;
+            hipLaunchKernelGGL(wgrad_reduce_partial_kernel, dim3((9 * 64 * 32 / 4 + 255) / 256, WGR_PARTS), dim3(256), 0, st,
+                               (const float*)p.slab, d.wg2_blocks, 9 * 64 * 32 / 4, part);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 32 + 255) / 256), dim3(256), 0, st, (const float*)part, WGR_PARTS, 32, 64,
+                               g->conv_w[1]);
+        }
         hipLaunchKernelGGL(prep_conv_wT_bf16x3_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], p.wcb2t, 32, 64);
         constexpr size_t ldsd = conv_bf16x6_lds_bytes(4, 2);
         if (sir_conv_ns())

@@ -281,20 +281,31 @@ static __global__ __launch_bounds__(256) void colsum_partial_kernel(const float*
         out[(size_t)blockIdx.y * n_cols + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// dfc_w[j][c] = sum_b dlogits[b][j] ctx[b][c];  dfc_b[j] = sum_b dlogits[b][j]     (one block per class)
+// dfc_w[j][c] = sum_b dlogits[b][j] ctx[b][c];  dfc_b[j] = sum_b dlogits[b][j]
+//   grid (C, 2): block (j, half) owns 256 columns c; the dlogits column is staged in LDS once and the loop over
+//   the batch is unrolled so that the ctx loads pipeline (the first version ran one dependent load per iteration)
 static __global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __restrict__ dlogits, const float* __restrict__ ctx,
                                                         float* __restrict__ dw, float* __restrict__ db, int B, int C) {
-    const int j = blockIdx.x;
-    for (int c = threadIdx.x; c < 512; c += 256) {
-        float a = 0.0f;
-        for (int b = 0; b < B; ++b) a = fmaf(dlogits[(size_t)b * C + j], ctx[(size_t)b * 512 + c], a);
-        dw[(size_t)j * 512 + c] = a;
+    __shared__ float dl[1024];
+    const int j = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    float a = 0.0f, sb = 0.0f;
+    for (int b0 = 0; b0 < B; b0 += 1024) {
+        const int nb = min(1024, B - b0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += 256) dl[i] = dlogits[(size_t)(b0 + i) * C + j];
+        __syncthreads();
+        int b = 0;
+        for (; b + 8 <= nb; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ctx[(size_t)(b0 + b + u) * 512 + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a = fmaf(dl[b + u], v[u], a); sb += dl[b + u]; }
+        }
+        for (; b < nb; ++b) { a = fmaf(dl[b], ctx[(size_t)(b0 + b) * 512 + c], a); sb += dl[b]; }
     }
-    if (threadIdx.x == 0) {
-        float s = 0.0f;
-        for (int b = 0; b < B; ++b) s += dlogits[(size_t)b * C + j];
-        db[j] = s;
-    }
+    dw[(size_t)j * 512 + c] = a;
+    if (c == 0) db[j] = sb;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -878,14 +889,37 @@ __global__ __launch_bounds__(576) void conv_wgrad_mfma_kernel(const float* __res
             }
 }
 
-// dW[co][ci][tap] = sum_blk slab[blk][tap][co][ci]
-static __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk, int cin, int cout, float* __restrict__ dw) {
+// dW[co][ci][tap] = sum_blk slab[blk][tap][co][ci], in two ordered (deterministic) passes: WGR_PARTS partial sums over
+// interleaved-free contiguous slab ranges (grid.y), then their sum + the transpose to the torch layout
+constexpr int WGR_PARTS = 16;
+static __global__ __launch_bounds__(256) void wgrad_reduce_partial_kernel(const float* __restrict__ slab, int nblk, int total4,
+                                                                     float* __restrict__ part) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // float4 index into one slab
+    if (idx >= total4) return;
+    const int per = (nblk + WGR_PARTS - 1) / WGR_PARTS, k0 = blockIdx.y * per, k1 = min(nblk, k0 + per);
+    const float4* s4 = reinterpret_cast<const float4*>(slab);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = k0;
+    for (; k + 4 <= k1; k += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = s4[(size_t)(k + u) * total4 + idx];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    for (; k < k1; ++k) {
+        const float4 v = s4[(size_t)k * total4 + idx];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(part)[(size_t)blockIdx.y * total4 + idx] = acc;
+}
+static __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nparts, int cin, int cout, float* __restrict__ dw) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // (tap, co, ci), ci fastest
     const int total = 9 * cout * cin;
     if (idx >= total) return;
     const int ci = idx % cin, co = (idx / cin) % cout, tap = idx / (cin * cout);
     float s = 0.0f;
-    for (int k = 0; k < nblk; ++k) s += slab[(size_t)k * total + idx];
+    for (int k = 0; k < nparts; ++k) s += part[(size_t)k * total + idx];
     dw[((size_t)co * cin + ci) * 9 + tap] = s;
 }
 

@@ -118,3 +118,20 @@ def test_fast_ref_equals_explicit_forward(sd, model_golden):
     sds = cases.sharp_head(sd, model_golden["sharp_fc_bias"])
     lg = model_ref.FastRef(sds)(inp["x_sharp64"])
     assert (lg.argmax(1).numpy() == model_golden["sharp64_argmax"]).all()
+
+
+def test_train_ref_matches_reference_training_step(sd, model_golden):
+    """The nn.Module timed by bench.py's CPU training baseline reproduces the reference's own step."""
+    inp = cases.model_inputs()
+    m = model_ref.TrainRef(sd, 31).train()
+    m.gru.dropout = 0.0                                    # the golden step was generated without dropout
+    opt = torch.optim.Adam(m.parameters(), lr=cases.LR, weight_decay=cases.WEIGHT_DECAY)
+    opt.zero_grad(set_to_none=True)
+    logits = m(inp["x_train8"])
+    loss = torch.nn.functional.cross_entropy(logits, inp["y_train8"])
+    loss.backward()
+    assert abs(loss.item() - float(model_golden["train8_loss"])) < 1e-5
+    np.testing.assert_allclose(logits.detach().numpy(), model_golden["train8_logits"], rtol=0, atol=2e-5)
+    for name, p in m.named_parameters():
+        norm = float(model_golden[f"grad_norm/{name}"])
+        assert abs(p.grad.double().norm().item() - norm) <= 1e-3 * norm + 1e-7, name
