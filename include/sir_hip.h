@@ -73,6 +73,30 @@ const char* sir_last_error(void);
 int sir_create(const sir_feature_config* cfg, sir_handle** out);
 int sir_destroy(sir_handle* h);
 
+/* ---- waveform front-end --------------------------------------------
+ * sir_mix_to_mono replaces `waveform = torch.mean(waveform, dim=0, keepdim=True)` after
+ *   torchaudio.load (scripts/precompute_features.py:47-51, scripts/dataset.py:126-130,
+ *   scripts/test_model.py:62-66) for a batch of decoded clips.
+ *   pcm   : [batch][clip_stride] INTERLEAVED samples (frame-major, `channels` per frame), i16 or f32
+ *           (dtype = SIR_WAVE_*); i16 is dequantised as s / 32768 first, as torchaudio.load does
+ *   frames: device int32[batch] (NULL = all max_frames); out rows are zero beyond frames[b]
+ *   out   : [batch][out_stride] f32 mono
+ * sir_resample replaces `torchaudio.transforms.Resample(sr, 16000)(waveform)`
+ *   (precompute_features.py:54-56, dataset.py:132-135, test_model.py:68-72): sinc_interp_hann,
+ *   lowpass_filter_width 6, rolloff 0.99, output length ceil(new * length / orig) per clip.
+ *   wave/lengths as in sir_features_fwd; out: [batch][out_stride] f32, zero beyond the clip's output
+ *   length (clamped to max_out_len); out_lengths: optional device int32[batch].
+ *   The first call for a rate pair builds the filter table on the host and uploads it (host-synchronous,
+ *   two small hipMallocs owned by the handle); later calls only launch.
+ * sir_resample_out_len: host helper, ceil(new * length / orig) with gcd-reduced rates (-1 on bad input). */
+int sir_mix_to_mono(sir_handle* h, const void* pcm, int dtype, int channels, int64_t clip_stride,
+                    const int32_t* frames, int batch, int max_frames, float* out, int64_t out_stride,
+                    void* stream);
+int sir_resample_out_len(int length, int orig_freq, int new_freq);
+int sir_resample(sir_handle* h, const void* wave, int wave_dtype, int64_t wave_stride,
+                 const int32_t* lengths, int batch, int max_len, int orig_freq, int new_freq, float* out,
+                 int64_t out_stride, int max_out_len, int32_t* out_lengths, void* stream);
+
 /* ---- feature path --------------------------------------------------------------------------
  * sir_features_fwd replaces, for a whole batch in one launch pair,
  *   AudioFeatureExtractor.extract_features  scripts/precompute_features.py:59-73

@@ -107,6 +107,7 @@ extern "C" int sir_destroy(sir_handle* h) {
     if (!h) return SIR_OK;
     (void)hipFree(h->tw512); (void)hipFree(h->tw1024); (void)hipFree(h->window);
     (void)hipFree(h->melw); (void)hipFree(h->mel_start);
+    for (auto& t : h->resample_tables) { (void)hipFree(t.taps); (void)hipFree(t.first); }
     for (auto& r : h->prof_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : h->prof_free) (void)hipEventDestroy(e);
     delete h;

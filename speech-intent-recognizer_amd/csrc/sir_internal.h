@@ -21,6 +21,14 @@ enum SirKernelId {
 
 struct SirProfRec { int id; hipEvent_t e0, e1; };
 
+// polyphase resampling filter of one (orig_freq, new_freq) pair (frontend.hip), device tables
+struct sir_resample_table {
+    int orig_freq, new_freq;    // as passed by the caller
+    int orig, nw, width, L;     // gcd-reduced rates, torchaudio's `width`, taps kept per phase
+    float* taps;                // [nw][L]
+    int* first;                 // [nw] index (in torchaudio's kernel row) of the first kept tap
+};
+
 struct sir_handle {
     // event profiling state (host only)
     int prof_mode;      // 0 off, 1 every kernel, 2 only prof_only
@@ -40,6 +48,7 @@ struct sir_handle {
     float* melw;        // [max_taps][64]  tap-major, zero padded
     int* mel_start;     // [64] first FFT bin of each filter
     int max_taps;
+    std::vector<sir_resample_table> resample_tables;   // built on first use of a rate pair
 };
 
 void sir_set_error(const char* fmt, ...);

@@ -105,6 +105,53 @@ class HipFeaturizer:
         return out
 
 
+    # ---- waveform front-end (channel mix-down, sample-rate conversion) -----------------------------
+    def mix_to_mono(self, pcm, channels, frames=None):
+        """pcm: [B, frames * channels] interleaved int16 or float32 on the GPU -> [B, frames] float32
+        (``torch.mean(waveform, dim=0)`` of precompute_features.py:50-51 after torchaudio.load's /32768)."""
+        _native.require_hip(pcm, frames)
+        if pcm.dim() != 2 or pcm.stride(1) != 1 or pcm.shape[1] % channels:
+            raise _native.SirError("pcm must be [B, frames * channels] with unit inner stride")
+        dt = {torch.float32: _native.WAVE_F32, torch.int16: _native.WAVE_I16}.get(pcm.dtype)
+        if dt is None:
+            raise _native.SirError(f"unsupported sample dtype {pcm.dtype}")
+        bsz, max_frames = pcm.shape[0], pcm.shape[1] // channels
+        if frames is not None:
+            frames = frames.to(torch.int32).contiguous()
+        out = torch.empty((bsz, max_frames), dtype=torch.float32, device=pcm.device)
+        rc = _native.lib().sir_mix_to_mono(self._h, pcm.data_ptr(), dt, channels, pcm.stride(0),
+                                           frames.data_ptr() if frames is not None else None, bsz, max_frames,
+                                           out.data_ptr(), out.stride(0), _native.current_stream_ptr())
+        _native.check(rc, "sir_mix_to_mono")
+        return out
+
+    def resample(self, wave, orig_freq, new_freq=None, lengths=None):
+        """``torchaudio.transforms.Resample(orig_freq, new_freq)`` (precompute_features.py:54-56) for a batch:
+        wave [B, L] float32/int16 on the GPU, lengths int32 [B] -> ([B, ceil(new * L / orig)] float32, out lengths)."""
+        new_freq = self.sample_rate if new_freq is None else new_freq
+        _native.require_hip(wave, lengths)
+        if wave.dim() != 2 or wave.stride(1) != 1:
+            raise _native.SirError("wave must be [B, L] with unit inner stride")
+        dt = {torch.float32: _native.WAVE_F32, torch.int16: _native.WAVE_I16}.get(wave.dtype)
+        if dt is None:
+            raise _native.SirError(f"unsupported waveform dtype {wave.dtype}")
+        bsz, max_len = wave.shape
+        if lengths is None:
+            lengths = torch.full((bsz,), max_len, dtype=torch.int32, device=wave.device)
+        lengths = lengths.to(torch.int32).contiguous()
+        if int(orig_freq) == int(new_freq):
+            return (wave if wave.dtype == torch.float32 else wave.float() / 32768.0), lengths
+        lib = _native.lib()
+        max_out = lib.sir_resample_out_len(max_len, int(orig_freq), int(new_freq))
+        out = torch.empty((bsz, max_out), dtype=torch.float32, device=wave.device)
+        out_len = torch.empty((bsz,), dtype=torch.int32, device=wave.device)
+        rc = lib.sir_resample(self._h, wave.data_ptr(), dt, wave.stride(0), lengths.data_ptr(), bsz, max_len,
+                              int(orig_freq), int(new_freq), out.data_ptr(), out.stride(0), max_out,
+                              out_len.data_ptr(), _native.current_stream_ptr())
+        _native.check(rc, "sir_resample")
+        return out, out_len
+
+
 _featurizers = {}
 
 

@@ -42,47 +42,70 @@ class AudioFeatureExtractor:
             self._fz = get_featurizer(self.sample_rate, self.n_mels, self.n_fft, self.hop_length)
         return self._fz
 
-    # -- host side: decode, mono, truncate (precompute_features.py:47-61) ------------------------
+    # -- host side: decode only (precompute_features.py:47); mono / resample / truncate run on the GPU ----
     def _load(self, audio_path, max_duration):
+        """-> (interleaved samples 1-D int16|float32, channels, sample_rate), cut to what max_duration needs."""
         if not os.path.exists(audio_path):
             logger.error(f"File not found: {audio_path}")
             return None
-        waveform, sr = wav_io.read_wav(audio_path)
-        if waveform.shape[0] > 1:
-            waveform = torch.mean(waveform, dim=0, keepdim=True)
-        if sr != self.sample_rate:
-            # the reference resamples with torchaudio (sinc_interp_hann); not built yet on this path
-            raise wav_io.WavError(f"sample rate {sr} != {self.sample_rate}: resampling is not available")
-        max_samples = int(max_duration * self.sample_rate)
-        wave = waveform[0, :max_samples]
-        if wave.numel() <= self.n_fft // 2:
-            # torch.stft's reflect padding fails here in the reference, which then returns None
-            raise wav_io.WavError(f"clip too short for reflect padding ({wave.numel()} samples)")
-        return wave.contiguous()
+        data, ch, sr = wav_io.read_wav_interleaved(audio_path)
+        keep = int(max_duration * sr) + 256                      # + the resampling filter's support
+        if data.numel() > keep * ch:
+            data = data[: keep * ch]
+        return data, ch, sr
 
     def extract_batch(self, audio_paths, max_duration=5.0):
-        """Features for many files with one GPU pass -> list of ``FloatTensor[64, T]`` / ``None``."""
-        waves, slots = [], []
+        """Features for many files -> list of ``FloatTensor[64, T]`` / ``None``.  Clips are grouped by
+        (channels, sample rate, sample type); each group is one mix-down launch (if multi-channel), one
+        resampling launch (if the rate is not ``self.sample_rate``) and one feature launch pair."""
+        out = [None] * len(audio_paths)
+        groups = {}
         for i, p in enumerate(audio_paths):
             try:
-                w = self._load(p, max_duration)
-            except Exception as e:  # swallow-and-continue, as the reference does
+                item = self._load(p, max_duration)
+            except Exception as e:  # swallow-and-continue, as the reference does (:77-79)
                 logger.error(f"Error processing {p}: {str(e)}")
-                w = None
-            if w is not None:
-                waves.append(w)
-                slots.append(i)
-        out = [None] * len(audio_paths)
-        if not waves:
-            return out
-        try:
-            feats, frames = self.features_from_waveforms(waves)
-        except Exception as e:
-            logger.error(f"Error processing batch of {len(waves)} clips: {str(e)}")
-            return out
-        for k, i in enumerate(slots):
-            out[i] = feats[k, :, : frames[k]].clone()
+                item = None
+            if item is not None:
+                data, ch, sr = item
+                groups.setdefault((ch, sr, data.dtype), []).append((i, data))
+        for (ch, sr, _), items in groups.items():
+            try:
+                feats, frames, ok = self._features_of_group([d for _, d in items], ch, sr, max_duration)
+            except Exception as e:
+                logger.error(f"Error processing batch of {len(items)} clips: {str(e)}")
+                continue
+            for k, (i, _) in enumerate(items):
+                if ok[k]:
+                    out[i] = feats[k, :, : frames[k]].clone()
+                else:
+                    # torch.stft's reflect padding fails on such a clip in the reference, which then returns None
+                    logger.error(f"Error processing {audio_paths[i]}: clip too short for reflect padding")
         return out
+
+    def _features_of_group(self, datas, channels, sr, max_duration):
+        fz = self._featurizer()
+        dev = fz.device
+        nfr = [int(d.numel()) // channels for d in datas]
+        host = torch.zeros((len(datas), max(nfr) * channels), dtype=datas[0].dtype).pin_memory()
+        for k, d in enumerate(datas):
+            host[k, : nfr[k] * channels] = d[: nfr[k] * channels]
+        wave = host.to(dev, non_blocking=True)
+        lens = torch.tensor(nfr, dtype=torch.int32, device=dev)
+        if channels > 1:
+            wave = fz.mix_to_mono(wave, channels, lens)                       # precompute_features.py:50-51
+        if sr != self.sample_rate:
+            wave, lens = fz.resample(wave, sr, self.sample_rate, lens)       # :54-56
+        max_samples = int(max_duration * self.sample_rate)
+        lens = torch.clamp(lens, max=max_samples)                             # :59-61
+        wave = wave[:, :max_samples]
+        if wave.stride(1) != 1 or (wave.stride(0) * wave.element_size()) % 16:
+            wave = wave.contiguous()
+        host_lens = lens.cpu().tolist()
+        ok = [n > self.n_fft // 2 for n in host_lens]
+        frames = [fz.num_frames(n) for n in host_lens]
+        feats = fz(wave, lens, t_pad=max(frames))
+        return feats.cpu(), frames, ok
 
     def features_from_waveforms(self, waves):
         """list of float32 [L_i] (CPU) -> (features [N, 64, Tmax] on the CPU, frame counts)."""

@@ -49,7 +49,7 @@ def read_wav(path, prefer_int16=False):
     if tag == 1 and bits == 16:
         x = np.frombuffer(raw, dtype="<i2", count=(size // 2 // ch) * ch).reshape(-1, ch).T
         if prefer_int16:
-            return torch.from_numpy(np.ascontiguousarray(x)), sr
+            return torch.from_numpy(np.array(x, dtype=np.int16, order="C")), sr
         return torch.from_numpy(x.astype(np.float32) / 32768.0), sr
     if tag == 1 and bits == 8:
         x = np.frombuffer(raw, dtype=np.uint8, count=(size // ch) * ch).reshape(-1, ch).T
@@ -65,8 +65,22 @@ def read_wav(path, prefer_int16=False):
         return torch.from_numpy(x.astype(np.float32) / float(1 << 31)), sr
     if tag == 3 and bits == 32:
         x = np.frombuffer(raw, dtype="<f4", count=(size // 4 // ch) * ch).reshape(-1, ch).T
-        return torch.from_numpy(np.ascontiguousarray(x)), sr
+        return torch.from_numpy(np.array(x, dtype=np.float32, order="C")), sr
     raise WavError(f"{path}: unsupported WAVE format tag={tag} bits={bits}")
+
+
+def read_wav_interleaved(path):
+    """-> (samples 1-D tensor, frame-major interleaved, int16 for PCM16 files else float32; channels;
+    sample_rate).  The GPU front-end (sir_mix_to_mono / sir_resample) dequantises and mixes channels."""
+    with open(path, "rb") as f:
+        head = f.read(12)
+    if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+        raise WavError(f"{path}: not a RIFF/WAVE file")
+    x, sr = read_wav(path, prefer_int16=True)                 # [channels, frames]
+    ch = x.shape[0]
+    if ch == 1:
+        return x[0].contiguous(), 1, sr
+    return x.t().contiguous().reshape(-1), ch, sr
 
 
 def write_wav_pcm16(path, samples, sample_rate):

@@ -10,7 +10,7 @@ import pandas as pd
 import pytest
 import torch
 
-from oracle import features_ref
+from oracle import features_ref, resample_ref
 from sir_amd import synth
 from sir_amd.scripts.utils import wav_io
 
@@ -31,7 +31,7 @@ def _make_corpus(root, n=24):
             wav_io.write_wav_pcm16(path, torch.stack([clips[i, :length], clips[(i + 1) % n, :length]]), 16000)
         elif i == 5:                                 # shorter than the reflect pad: reference returns None
             wav_io.write_wav_pcm16(path, clips[i, :300], 16000)
-        elif i == 7:                                 # other sample rate: resampling not on this path -> None
+        elif i == 7:                                 # other sample rate: resampled on the GPU (precompute_features.py:54-56)
             wav_io.write_wav_pcm16(path, clips[i, :length], 22050)
         elif i == 9:
             path = os.path.join(root, "missing.wav")  # never written
@@ -62,11 +62,11 @@ def test_precompute_dataset_train_evaluate(tmp_path):
         pf.precompute_dataset_features(csvs[split], cache_dir)
     feats = torch.load(cache)
     assert os.path.basename(cache) == "train_data_features.pt"
-    bad = {rows[i]["path"] for i in (5, 7, 9)}
+    bad = {rows[i]["path"] for i in (5, 9)}
     assert set(feats) == {r["path"] for r in rows[:16]} - bad       # failures are skipped, not raised
     for path, item in feats.items():
         wave, sr = wav_io.read_wav(path)
-        ref = features_ref.extract_features_f32(wave.mean(0))
+        ref = features_ref.extract_features_f32(resample_ref.resample(wave.mean(0, keepdim=True), sr, 16000)[0])
         got = item["features"]
         assert got.shape == ref.shape and isinstance(item["label"], str)
         assert ((got - ref).abs() <= 1e-4 * ref.abs().clamp(min=1.0)).all(), path
