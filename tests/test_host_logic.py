@@ -152,3 +152,59 @@ def test_gloo_world2_gradient_mean_and_broadcast(tmp_path):
     out = str(tmp_path / "res.txt")
     mp.spawn(_gloo_worker, args=(2, 29611, out), nprocs=2, join=True)
     assert open(out).read() == "ok"
+
+
+# ---- CSV preprocessing and pipeline orchestration (host-only; reference preprocess_fsc.py / run_pipeline.py) ----
+def _write_corpus(root, n=6):
+    import pandas as pd
+    from sir_amd.scripts.utils import wav_io
+    os.makedirs(root, exist_ok=True)
+    rows = []
+    g = torch.Generator().manual_seed(1)
+    for i in range(n):
+        p = os.path.join(root, f"u{i}.wav")
+        wav_io.write_wav_pcm16(p, 0.1 * torch.randn(50 if i == 2 else 4000, generator=g), 16000)   # u2 is too short
+        rows.append({"audio_path": p, "action": ["on", "off"][i % 2], "object": ["lamp", "heat", "music"][i % 3]})
+    rows.append({"audio_path": os.path.join(root, "nope.wav"), "action": "on", "object": "lamp"})
+    return pd.DataFrame(rows)
+
+
+def test_preprocess_dataset_outputs(tmp_path):
+    import json
+    import pandas as pd
+    from sir_amd.scripts import preprocess_fsc as pp
+    df = _write_corpus(str(tmp_path / "wav"))
+    for split in ("train", "valid", "test"):
+        df.to_csv(tmp_path / f"{split}.csv", index=False)
+    out = pp.preprocess_dataset(str(tmp_path / "train.csv"), str(tmp_path / "valid.csv"), str(tmp_path / "test.csv"),
+                                str(tmp_path / "processed"))
+    assert set(out) == {"train_csv", "valid_csv", "test_csv", "label_map"}
+    got = pd.read_csv(out["train_csv"])
+    assert os.path.basename(out["train_csv"]) == "train_data.csv" and len(got) == 5      # short + missing files dropped
+    assert {"path", "label"} <= set(got.columns) and set(got["label"]) == {"on_lamp", "off_heat", "off_lamp", "on_heat", "off_music"}
+    lm = json.load(open(out["label_map"]))
+    assert lm == {l: i for i, l in enumerate(sorted(set(got["label"])))}
+    # failure conventions: unreadable CSV -> None, not an exception
+    assert pp.preprocess_dataset(str(tmp_path / "absent.csv"), str(tmp_path / "valid.csv"), str(tmp_path / "test.csv"),
+                                 str(tmp_path / "p2")) is None
+    assert not pp.validate_audio(str(tmp_path / "train.csv"))                              # not a WAVE file
+
+
+def test_run_pipeline_stage_commands(tmp_path):
+    from sir_amd import run_pipeline as rp
+    cfg = {"cache_dir": "c", "save_path": "ck"}
+    one = rp.stage_commands("cfg.yaml", cfg, "tr.csv", "va.csv", "te.csv", "lm.json", gpus=1)
+    assert one["train"][1:4] == ["-m", "sir_amd.scripts.train", "--config"] and "--val_csv" in one["train"]
+    assert one["precompute"][1:3] == ["-m", "sir_amd.scripts.precompute_features"] and one["precompute"][-1] == "lm.json"
+    assert one["evaluate"][-2:] == ["--model_path", os.path.join("ck", "best_model.pt")]
+    eight = rp.stage_commands("cfg.yaml", cfg, "tr.csv", "va.csv", "te.csv", "lm.json", gpus=8)
+    assert "torch.distributed.run" in eight["train"] and "--nproc-per-node=8" in eight["train"]
+    assert eight["train"][eight["train"].index("--master-addr") + 1] == "127.0.0.1"
+    # missing data files stop the pipeline with False (run_pipeline.py:111-113), nothing is raised
+    (tmp_path / "cfg.yaml").write_text("train_csv: /nonexistent/a.csv\nvalid_csv: /nonexistent/b.csv\ntest_csv: /nonexistent/c.csv\n")
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        assert rp.run_pipeline(str(tmp_path / "cfg.yaml")) is False
+    finally:
+        os.chdir(cwd)
