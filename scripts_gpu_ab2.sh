@@ -1,0 +1,18 @@
+#!/bin/bash
+# like scripts_gpu_ab.sh but inference-only and single pass per value: ./scripts_gpu_ab2.sh VAR v1 v2 ...
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R; mkdir -p gpurun_out
+VAR=$1; shift
+LAST="${@: -1}"
+env $VAR=$LAST timeout -k 10 600 python -m pytest tests/test_model_gpu.py -q -x > gpurun_out/ab_tests.log 2>&1; rc=$?
+tail -2 gpurun_out/ab_tests.log
+if [ $rc -ne 0 ]; then grep -E "^E|Error" gpurun_out/ab_tests.log | head -20; exit $rc; fi
+for v in "$@"; do
+  env $VAR=$v timeout -k 10 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-train > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { tail -5 gpurun_out/ab_$v.err; exit 1; }
+  python - <<PY
+import json
+d=json.loads(open("gpurun_out/ab_$v.json").read().strip().splitlines()[-1])
+print("$VAR=$v", d["value"], d["ms_per_step"], {k: round(x*1e3,1) for k,x in d["kernels_avg_ms"].items() if x})
+PY
+done

@@ -45,7 +45,8 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     }
     sir_handle* h = new sir_handle();
     h->prof_mode = 0; h->prof_only = -1;
-    h->weights_version = 0; h->prep_version = 0; h->prep_ws = nullptr; h->prep_key = -1;
+    h->weights_version = 0; h->prep_next = 0;
+    for (auto& e : h->prep) { e.ws = nullptr; e.version = 0; e.key = -1; }
     h->tw512 = nullptr; h->tw1024 = nullptr; h->window = nullptr; h->melw = nullptr; h->mel_start = nullptr;
     h->cfg = *cfg;
     h->cfg.window = nullptr;

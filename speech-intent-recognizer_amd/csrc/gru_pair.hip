@@ -4,7 +4,12 @@
 #include <stdlib.h>
 #include "gru_pair_kernel.h"
 
-size_t sir_gru_pair_xbuf_bytes(int batch) { return (size_t)((batch + GP_BW - 1) / GP_BW) * 2 * 2 * 2 * GP_BW * GP_UH * 8; }
+// exchange-granule workspace shared by the pair and the quad kernels: the larger of the two
+size_t sir_gru_pair_xbuf_bytes(int batch) {
+    const size_t pair = (size_t)((batch + GP_BW - 1) / GP_BW) * 2 * 2 * 2 * GP_BW * GP_UH * 8;
+    const size_t quad = sir_gru_quad_xbuf_bytes(batch);
+    return pair > quad ? pair : quad;
+}
 size_t sir_gru_pair_flag_bytes(int batch) { return (size_t)((batch + GP_BW - 1) / GP_BW) * 2 * 2 * 4 + 256; }
 
 int sir_launch_gru_pair(hipStream_t st, bool save, const float* gi, const float* whh0, const float* whh1, const float* bhh0,
@@ -17,7 +22,7 @@ int sir_launch_gru_pair(hipStream_t st, bool save, const float* gi, const float*
     }
     const size_t npairs = (B + GP_BW - 1) / GP_BW;
     unsigned int* status = flags + npairs * 2 * 2;
-    SIR_HIP_TRY(hipMemsetAsync(xbuf, 0, sir_gru_pair_xbuf_bytes(B), st));    // tags are re-armed before every launch
+    SIR_HIP_TRY(hipMemsetAsync(xbuf, 0, (size_t)((B + GP_BW - 1) / GP_BW) * 2 * 2 * 2 * GP_BW * GP_UH * 8, st));    // tags are re-armed before every launch
     const dim3 grid((unsigned)(npairs * 2), 2);
     static const int nowait = getenv("SIR_GRU_DBG_NOWAIT") ? atoi(getenv("SIR_GRU_DBG_NOWAIT")) : 0;
     if (save)

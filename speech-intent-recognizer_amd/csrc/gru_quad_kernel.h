@@ -1,0 +1,231 @@
+// Quad-workgroup GRU recurrence on the bf16 matrix cores (bf16x6 products, fp32 accuracy).
+//
+// gru_pair_kernel computes W_hh h with fp32 FMAs and is bound by VALU issue (~64 us of FMA issue per
+// layer at batch 256 plus 25 dependent exchanges).  Here the recurrent product runs on MFMA:
+//   * one CLUSTER of four workgroups owns 16 utterances of one direction for all S steps;
+//   * workgroup q owns hidden units [64 q, 64 q + 64), i.e. 192 gate rows of W_hh; its 4 waves each own 16
+//     units x 3 gates = three 16 x 256 row tiles, kept for the whole sequence IN REGISTERS as bf16x3 planes
+//     (3 gates x 8 k-steps x 3 planes x 4 VGPRs = 288 VGPRs per lane: one wave per SIMD, 512-register budget);
+//   * per step a wave issues 3 tiles x 8 k-steps x 6 plane products = 144 v_mfma_f32_16x16x32_bf16 with
+//     A = W tile (rows = units) and B = h^T (columns = the 16 utterances), so that a lane ends up with the
+//     r, z, n pre-activations of 4 consecutive units of ONE utterance in its three accumulators: the gate
+//     arithmetic is lane-local;
+//   * h lives in LDS as three bf16 planes [utterance][k] (double-buffered by step parity, rows padded to
+//     528 B); every workgroup needs all 256 units, so after each step the four quarters exchange their
+//     64 x 16 new values through global memory: one 8-byte granule per value = {tag = step + 1 (16 bit),
+//     hi, mid, lo bf16} written by ONE agent-scope relaxed 64-bit store and polled with agent-scope relaxed
+//     loads until the tag matches (recipe R2 of cdna_hip_programming.md G16, as in gru_pair_kernel: the
+//     data is the flag).  Granule buffers alternate by step parity and are zeroed before every launch.
+// Results differ from the fp32-FMA kernel only by the bf16x6 product rounding (~2^-24 relative per product).
+#pragma once
+#include "bf16x6_kernels.h"
+
+constexpr int GQ_NU = 16;                 // utterances per cluster (the MFMA N dimension)
+constexpr int GQ_UQ = 64;                 // hidden units per workgroup
+constexpr int GQ_THREADS = 256;
+constexpr int GQ_ROWB = 256 * 2 + 16;     // bytes per utterance row of one h plane (pad: conflict-free b128 reads)
+constexpr int GQ_PLANEB = GQ_NU * GQ_ROWB;
+constexpr int GQ_BUFB = 3 * GQ_PLANEB;    // one parity buffer: 25,344 B
+constexpr size_t GQ_LDS_BYTES = 2 * (size_t)GQ_BUFB;
+constexpr unsigned GQ_SPIN_LIMIT = 1u << 22;
+constexpr size_t GQ_XBUF_PER_CLUSTER = (size_t)2 * 4 * GQ_NU * GQ_UQ * 8;   // [parity][quarter][utterance][unit] granules
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// gate non-linearities from the hardware exp2 / rcp (1 ulp each) instead of the libm expf / tanhf / IEEE division:
+// this kernel evaluates 12 of them per lane and step on ONE wave per SIMD, where the ~110-instruction libm
+// forms cost ~1 us per step.  Absolute error ~1e-7 (sigmoid) / ~2e-7 (tanh), far inside the 2e-5 logit tolerance.
+__device__ __forceinline__ float gq_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float gq_tanh(float x) {
+    // 1 - 2 / (1 + e^{2x}); saturates cleanly: e^{2x} -> inf gives 1, -> 0 gives -1
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x));
+}
+
+// xbuf   [clusters][2 parity][4 quarters][16 utterances][64 units] 8-byte granules, zeroed before every launch
+// status set to 1 if a spin times out (results are then invalid; cannot happen while a cluster is co-resident)
+template <bool SAVE>
+__global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
+    const float* __restrict__ gi, const float* __restrict__ whh0, const float* __restrict__ whh1,
+    const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ y, int B, int S,
+    float* __restrict__ gates, unsigned long long* xbuf, unsigned int* status, int dbg = 0) {
+    // dbg (timing experiments only, results invalid): bit 0 = do not wait for the granules, bit 1 = skip the MFMAs,
+    // bit 2 = skip publish + receive
+    extern __shared__ __attribute__((aligned(16))) unsigned char qlds[];
+    const int q = blockIdx.x, cluster = blockIdx.y;
+    const int dir = cluster & 1, grp = cluster >> 1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 15, kg = lane >> 4;                 // MFMA column (utterance) / k-group and D row group
+    const int b = grp * GQ_NU + n;
+    const bool bvalid = b < B;
+    const int u0 = q * GQ_UQ + wv * 16 + kg * 4;             // first of this lane's 4 hidden units (D rows 4 kg .. 4 kg + 3)
+    const float* __restrict__ whh = dir ? whh1 : whh0;       // [768][256]
+    const float* __restrict__ bhh = dir ? bhh1 : bhh0;
+    unsigned long long* xc = xbuf + (size_t)cluster * (2 * 4 * GQ_NU * GQ_UQ);
+
+    // ---- resident weights: A fragments of the three gate tiles, bf16x3 planes --------------------------
+    bf16x8 wf[3][8][3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const float* wrow = whh + (size_t)(g * 256 + q * GQ_UQ + wv * 16 + n) * 256 + kg * 8;   // A row = lane & 15
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float4 v0 = *reinterpret_cast<const float4*>(wrow + s * 32);
+            const float4 v1 = *reinterpret_cast<const float4*>(wrow + s * 32 + 4);
+            uint2 h0, m0, l0, h1, m1, l1;
+            split3_quad(v0, h0, m0, l0);
+            split3_quad(v1, h1, m1, l1);
+            wf[g][s][0] = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+            wf[g][s][1] = __builtin_bit_cast(bf16x8, make_uint4(m0.x, m0.y, m1.x, m1.y));
+            wf[g][s][2] = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+        }
+    }
+    float4 bh[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bh[g] = *reinterpret_cast<const float4*>(bhh + g * 256 + u0);
+    for (int i = tid; i < (int)(GQ_LDS_BYTES / 16); i += GQ_THREADS) reinterpret_cast<uint4*>(qlds)[i] = make_uint4(0, 0, 0, 0);
+    float4 hprev = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    // gate pre-activations of the input side, fetched one step ahead
+    float4 gin[3];
+    auto load_gi = [&](int t, float4 (&dst)[3]) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) dst[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bvalid) {
+            const float* gp = gi + ((size_t)b * S + t) * 1536 + dir * 768 + u0;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) dst[g] = *reinterpret_cast<const float4*>(gp + g * 256);
+        }
+    };
+    load_gi(dir ? S - 1 : 0, gin);
+    const int frag_off = n * GQ_ROWB + kg * 16;              // this lane's chunk inside a k-step of an h plane row
+    // receive role: thread = (utterance rn, 4-unit group ru4) of each of the three other quarters
+    const int rn = tid >> 4, ru4 = tid & 15;
+
+    for (int step = 0; step < S; ++step) {
+        const int t = dir ? (S - 1 - step) : step;
+        float4 gcur[3] = {gin[0], gin[1], gin[2]};
+        if (step + 1 < S) load_gi(dir ? (S - 2 - step) : step + 1, gin);
+        const unsigned char* hb = qlds + (step & 1) * GQ_BUFB;
+        unsigned char* hnb = qlds + ((step + 1) & 1) * GQ_BUFB;
+
+        // ---- W_hh h on the matrix cores ---------------------------------------------------------------
+        f32x4_t acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        // all 24 h fragments are read before the first MFMA (pinned): one wave per SIMD has nothing else to hide
+        // the LDS latency behind, and the compiler otherwise reads each fragment right before its use
+        bf16x8 hf[8][3];
+        if (!(dbg & 2)) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                hf[s][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(hb + p * GQ_PLANEB + frag_off + s * 64));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
+#pragma unroll
+            for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g][s][PA[t6]], hf[s][PB[t6]], acc[g], 0, 0, 0);
+        }
+        }
+
+        // ---- gates for 4 units x 1 utterance ------------------------------------------------------------
+        float hn4[4], r4[4], z4[4], n4[4], hh4[4];
+        const float gr[4] = {gcur[0].x, gcur[0].y, gcur[0].z, gcur[0].w}, gz[4] = {gcur[1].x, gcur[1].y, gcur[1].z, gcur[1].w};
+        const float gn[4] = {gcur[2].x, gcur[2].y, gcur[2].z, gcur[2].w};
+        const float br[4] = {bh[0].x, bh[0].y, bh[0].z, bh[0].w}, bz[4] = {bh[1].x, bh[1].y, bh[1].z, bh[1].w};
+        const float bn[4] = {bh[2].x, bh[2].y, bh[2].z, bh[2].w};
+        const float hp[4] = {hprev.x, hprev.y, hprev.z, hprev.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float hr = acc[0][j] + br[j], hz = acc[1][j] + bz[j];
+            hh4[j] = acc[2][j] + bn[j];
+            r4[j] = gq_sigmoid(gr[j] + hr);
+            z4[j] = gq_sigmoid(gz[j] + hz);
+            n4[j] = gq_tanh(gn[j] + r4[j] * hh4[j]);
+            hn4[j] = (1.0f - z4[j]) * n4[j] + z4[j] * hp[j];
+        }
+        hprev = make_float4(hn4[0], hn4[1], hn4[2], hn4[3]);
+
+        // ---- publish: own LDS planes (next parity) + one granule per value for the three other quarters ----
+        uint2 ph, pm, pl;
+        split3_quad(hprev, ph, pm, pl);
+        {
+            unsigned char* d = hnb + n * GQ_ROWB + u0 * 2;
+            *reinterpret_cast<uint2*>(d) = ph;
+            *reinterpret_cast<uint2*>(d + GQ_PLANEB) = pm;
+            *reinterpret_cast<uint2*>(d + 2 * GQ_PLANEB) = pl;
+        }
+        if (!(dbg & 4)) {
+            unsigned long long* gs = xc + (((size_t)(step & 1) * 4 + q) * GQ_NU + n) * GQ_UQ + (u0 - q * GQ_UQ);
+            const unsigned long long tag = (unsigned long long)(unsigned)(step + 1) << 48;
+            const unsigned hh_[4] = {ph.x & 0xFFFFu, ph.x >> 16, ph.y & 0xFFFFu, ph.y >> 16};
+            const unsigned mm_[4] = {pm.x & 0xFFFFu, pm.x >> 16, pm.y & 0xFFFFu, pm.y >> 16};
+            const unsigned ll_[4] = {pl.x & 0xFFFFu, pl.x >> 16, pl.y & 0xFFFFu, pl.y >> 16};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __hip_atomic_store(gs + j, tag | ((unsigned long long)hh_[j] << 32) | ((unsigned long long)mm_[j] << 16) | ll_[j],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (bvalid) {
+            *reinterpret_cast<float4*>(y + ((size_t)b * S + t) * 512 + dir * 256 + u0) = hprev;
+            if (SAVE) {
+                float* gsv = gates + (((size_t)b * S + t) * 2 + dir) * 1024 + u0;
+                *reinterpret_cast<float4*>(gsv) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+                *reinterpret_cast<float4*>(gsv + 256) = make_float4(z4[0], z4[1], z4[2], z4[3]);
+                *reinterpret_cast<float4*>(gsv + 512) = make_float4(n4[0], n4[1], n4[2], n4[3]);
+                *reinterpret_cast<float4*>(gsv + 768) = make_float4(hh4[0], hh4[1], hh4[2], hh4[3]);
+            }
+        }
+
+        // ---- receive the other three quarters' values of this step into the next-parity planes ------------
+        if (step + 1 < S && !(dbg & 4)) {
+            // all 12 granule loads of a poll round are independent (issued back to back, one wait); a round is
+            // repeated as a whole until every tag matches -- a per-granule retry serialises the round trips
+            unsigned long long v[3][4];
+            unsigned spins = 0;
+            const unsigned long long want = (unsigned long long)(unsigned)(step + 1);
+            const unsigned long long* src0 = xc + ((size_t)(step & 1) * 4 * GQ_NU + rn) * GQ_UQ + ru4 * 4;
+            for (;;) {
+#pragma unroll
+                for (int qi = 0; qi < 3; ++qi) {
+                    const int qs = qi + (qi >= q ? 1 : 0);   // source quarter != q
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        v[qi][j] = __hip_atomic_load(src0 + (size_t)qs * GQ_NU * GQ_UQ + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                bool ok = true;
+#pragma unroll
+                for (int qi = 0; qi < 3; ++qi)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ok = ok && ((v[qi][j] >> 48) == want);
+                if (ok || (dbg & 1)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > GQ_SPIN_LIMIT) { __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+#pragma unroll
+            for (int qi = 0; qi < 3; ++qi) {
+                const int qs = qi + (qi >= q ? 1 : 0);
+                uint2 rh, rm, rl;
+                rh.x = (unsigned)((v[qi][0] >> 32) & 0xFFFFu) | ((unsigned)((v[qi][1] >> 32) & 0xFFFFu) << 16);
+                rh.y = (unsigned)((v[qi][2] >> 32) & 0xFFFFu) | ((unsigned)((v[qi][3] >> 32) & 0xFFFFu) << 16);
+                rm.x = (unsigned)((v[qi][0] >> 16) & 0xFFFFu) | ((unsigned)((v[qi][1] >> 16) & 0xFFFFu) << 16);
+                rm.y = (unsigned)((v[qi][2] >> 16) & 0xFFFFu) | ((unsigned)((v[qi][3] >> 16) & 0xFFFFu) << 16);
+                rl.x = (unsigned)(v[qi][0] & 0xFFFFu) | ((unsigned)(v[qi][1] & 0xFFFFu) << 16);
+                rl.y = (unsigned)(v[qi][2] & 0xFFFFu) | ((unsigned)(v[qi][3] & 0xFFFFu) << 16);
+                unsigned char* d = hnb + rn * GQ_ROWB + (qs * GQ_UQ + ru4 * 4) * 2;
+                *reinterpret_cast<uint2*>(d) = rh;
+                *reinterpret_cast<uint2*>(d + GQ_PLANEB) = rm;
+                *reinterpret_cast<uint2*>(d + 2 * GQ_PLANEB) = rl;
+            }
+        }
+        __syncthreads();                                     // next-parity planes complete; this parity's reads are done
+    }
+}

@@ -89,6 +89,11 @@ extern "C" int sir_model_workspace_offsets(const sir_handle* h, int batch, int t
 
 #define SIR_KCHECK() SIR_HIP_TRY(hipGetLastError())
 
+int sir_gru_variant() {      // 0 = streaming fp32 kernel, 1 = paired fp32 kernel, 2 = quad MFMA kernel
+    static const int v = getenv("SIR_GRU_VARIANT") ? atoi(getenv("SIR_GRU_VARIANT")) : 2;
+    return v;
+}
+
 int sir_conv_ns() {
     static const int v = getenv("SIR_CONV_NS") ? atoi(getenv("SIR_CONV_NS")) : 1;
     return v;
@@ -140,13 +145,15 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     static const int gemm_variant = getenv("SIR_GEMM_VARIANT") ? atoi(getenv("SIR_GEMM_VARIANT")) : 2;
     static const int conv_bf16 = getenv("SIR_CONV_BF16X6") ? atoi(getenv("SIR_CONV_BF16X6")) : 1;
     // GRU variant: 1 = paired workgroups with W_hh resident on chip (default), 0 = single workgroup streaming W_hh
-    static const int gru_variant = getenv("SIR_GRU_VARIANT") ? atoi(getenv("SIR_GRU_VARIANT")) : 1;
+    const int gru_variant = sir_gru_variant();
     // ---- weight preparation -------------------------------------------------------------
     // skipped when the caller vouches (sir_model_set_weights_version) that the weights are the ones prepared
     // into this very workspace by the previous call
     const long long prep_key = ((long long)B << 32) | (unsigned)d.T;
-    const bool reuse_prep = h->weights_version != 0 && h->prep_version == h->weights_version && h->prep_ws == workspace &&
-                            h->prep_key == prep_key;
+    sir_handle::PrepEntry* pe = nullptr;
+    for (auto& e : h->prep)
+        if (e.ws == workspace) pe = &e;
+    const bool reuse_prep = pe && h->weights_version != 0 && pe->version == h->weights_version && pe->key == prep_key;
     if (!reuse_prep) {
     SirProfScope prof(h, SIR_K_PREP, st);
     if (!conv_bf16) {
@@ -170,7 +177,8 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
             hipLaunchKernelGGL(split3_kernel, dim3(192), dim3(256), 0, st, w->gru_w_ih[2 + dir], 512, wsl1 + (size_t)dir * 3 * 768 * 512, (size_t)768, 512);
         }
     }
-    h->prep_version = h->weights_version; h->prep_ws = workspace; h->prep_key = prep_key;
+    if (!pe) { pe = &h->prep[h->prep_next]; h->prep_next = (h->prep_next + 1) % 4; }
+    pe->ws = workspace; pe->version = h->weights_version; pe->key = prep_key;
     }
     SIR_KCHECK();
 
@@ -251,7 +259,10 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     hipLaunchKernelGGL((gemm_nt_bias_kernel<32, false>), ggrid, dim3(256), 0, st, x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
                        w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024); }
     { SirProfScope prof(h, SIR_K_GRU0, st);
-    if (gru_variant == 1) {
+    if (gru_variant == 2) {
+        const int rc = sir_launch_gru_quad(st, false, gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S, nullptr, gxb, gfl);
+        if (rc != SIR_OK) return rc;
+    } else if (gru_variant == 1) {
         const int rc = sir_launch_gru_pair(st, false, gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S, nullptr, gxb, gfl);
         if (rc != SIR_OK) return rc;
     } else
@@ -266,7 +277,10 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     hipLaunchKernelGGL((gemm_nt_bias_kernel<32, true>), ggrid, dim3(256), 0, st, y0, 512, w->gru_w_ih[2], w->gru_w_ih[3], 512,
                        w->gru_b_ih[2], w->gru_b_ih[3], gi, 1536, M, 768, 512); }
     { SirProfScope prof(h, SIR_K_GRU1, st);
-    if (gru_variant == 1) {
+    if (gru_variant == 2) {
+        const int rc = sir_launch_gru_quad(st, false, gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], y1, B, S, nullptr, gxb, gfl);
+        if (rc != SIR_OK) return rc;
+    } else if (gru_variant == 1) {
         const int rc = sir_launch_gru_pair(st, false, gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], y1, B, S, nullptr, gxb, gfl);
         if (rc != SIR_OK) return rc;
     } else

@@ -36,9 +36,11 @@ struct sir_handle {
     std::vector<SirProfRec> prof_pending;
     std::vector<hipEvent_t> prof_free;
     // prepared-weight cache key (sir_model_set_weights_version)
-    unsigned long long weights_version, prep_version;
-    const void* prep_ws;
-    long long prep_key;
+    unsigned long long weights_version;
+    // one entry per workspace that holds prepared weights (several streams may alternate workspaces)
+    struct PrepEntry { const void* ws; unsigned long long version; long long key; };
+    PrepEntry prep[4];
+    int prep_next;
     sir_feature_config cfg;
     int device;
     // feature tables (device)
@@ -100,5 +102,10 @@ int sir_features_launch(sir_handle* h, const void* wave, int wave_dtype, int64_t
 
 // generation of the bf16x6 input-projection GEMM (SIR_GEMM_BF16X6_GEN, default 2 = LDS-DMA kernel; 1 = first kernel)
 int sir_gemm_bf16x6_gen();
+// quad-workgroup MFMA GRU recurrence (gru_quad.hip); SIR_GRU_VARIANT=2 selects it
+size_t sir_gru_quad_xbuf_bytes(int batch);
+int sir_launch_gru_quad(hipStream_t st, bool save, const float* gi, const float* whh0, const float* whh1, const float* bhh0,
+                        const float* bhh1, float* y, int B, int S, float* gates, float* xbuf, unsigned int* status);
+int sir_gru_variant();
 // convolution generation (SIR_CONV_NS, default 1 = output channels split over the waves)
 int sir_conv_ns();

@@ -29,16 +29,19 @@ def load_config(config_path):
 @torch.no_grad()
 def predict_loader(model, loader, device):
     """argmax predictions and labels over a loader (the hot loop of evaluate.py:79-86)."""
+    from sir_amd.pipeline import BatchPipeline
     model.eval()
+    pipe = BatchPipeline(model, n_streams=2)          # consecutive batches alternate over two HIP streams
     preds, labels = [], []
-    for mel, label in tqdm(loader, desc="Evaluating"):
+    for i, (mel, label) in enumerate(tqdm(loader, desc="Evaluating")):
         if mel is None or label is None or mel.size(0) == 0:
             continue                      # the reference would crash here (evaluate.py:81); skip instead
-        _, pred = model.predict(mel.to(device, non_blocking=True))
+        _, pred = pipe.infer(i, mel.to(device, non_blocking=True))
         preds.append(pred)
         labels.append(label)
     if not preds:
         return [], []
+    pipe.synchronize()
     return torch.cat(preds).cpu().numpy(), torch.cat(labels).numpy()
 
 

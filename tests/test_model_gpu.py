@@ -105,3 +105,19 @@ def test_cpu_input_is_refused(sd):
     m = _model(sd)
     with pytest.raises(_native.SirError):
         m(torch.zeros(2, 64, 200))
+
+
+def test_batch_pipeline_matches_single_stream(sd):
+    """Batches alternating over HIP streams (sir_amd/pipeline.py) give bit-identical logits/argmax."""
+    from sir_amd.pipeline import BatchPipeline
+    m = CNNAudioGRU(31)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    xs = [cases.varied_features(16, 200, seed=100 + i).to(DEV) for i in range(6)]
+    ref = [m.predict(x) for x in xs]
+    torch.cuda.synchronize()
+    pipe = BatchPipeline(m, n_streams=3)
+    outs = [pipe.infer(i, x) for i, x in enumerate(xs)]
+    pipe.synchronize()
+    for (l0, a0), (l1, a1) in zip(ref, outs):
+        assert torch.equal(l0, l1) and torch.equal(a0, a1)
