@@ -14,7 +14,7 @@ int sir_launch_gru_quad(hipStream_t st, bool save, const float* gi, const float*
     }
     if (S >= 65535) { sir_set_error("gru_quad: %d steps exceed the 16-bit step tag", S); return SIR_EUNSUPPORTED; }
     const int clusters = ((B + GQ_NU - 1) / GQ_NU) * 2;
-    SIR_HIP_TRY(hipMemsetAsync(xbuf, 0, sir_gru_quad_xbuf_bytes(B), st));     // tags are re-armed before every launch
+    SIR_HIP_TRY(hipMemsetAsync(xbuf, 0, (size_t)clusters * GQ_XBUF_PER_CLUSTER, st));     // tags are re-armed before every launch
     const dim3 grid(4, (unsigned)clusters);
     static const int dbg = getenv("SIR_GRU_DBG") ? atoi(getenv("SIR_GRU_DBG")) : 0;
     if (save)

@@ -229,3 +229,8 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
         __syncthreads();                                     // next-parity planes complete; this parity's reads are done
     }
 }
+
+// Tried and removed: two utterance groups per cluster ("ping-pong": while group g's granules travel, group g^1
+// runs its MFMA/gate phase on the same resident weights; 64 workgroups instead of 128 at batch 256).  Correct,
+// but a phase took 4.1 us instead of the expected ~2.2 us (205 us per layer against 126 us), and with 2-3 HIP
+// streams the whole pipeline was no faster (348-378 k against 375-389 k utterances/s).
