@@ -352,11 +352,13 @@ static inline hipError_t launch_gemm_nt_bf16x6(hipStream_t st, int variant, cons
 // groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with the 8x4 patch bit layout of a fragment those 16
 // lanes then hit 16 different slots of the 256-byte bank line (the natural strides 30 and 54 give 2-way
 // conflicts on two lane pairs per group: SQ_LDS_BANK_CONFLICT = 50 % of LDS cycles).
-constexpr int conv_bf16x6_row_bytes(int PC) {
+// Padding costs LDS: the 32x8-pixel tiles (PC = 2) are left unpadded (48,960 B) so that THREE workgroups fit a CU --
+// measured 175 -> 154 us for conv2 and 229 -> 195 us for its data gradient, against ~3 % from the conflict-free reads.
+constexpr int conv_bf16x6_row_bytes(int PC, bool pad = true) {
     const int slots = (4 * PC + 2) * 3;
-    return (slots + ((4 - slots % 8) + 8) % 8) * 16;
+    return (pad ? slots + ((4 - slots % 8) + 8) % 8 : slots) * 16;
 }
-constexpr size_t conv_bf16x6_lds_bytes(int PR, int PC) { return (size_t)3 * (8 * PR + 2) * conv_bf16x6_row_bytes(PC); }
+constexpr size_t conv_bf16x6_lds_bytes(int PR, int PC, bool pad = true) { return (size_t)3 * (8 * PR + 2) * conv_bf16x6_row_bytes(PC, pad); }
 
 static __global__ void prep_conv_w_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin, int cout) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -561,14 +563,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(
 //   KNOCK (tools/bench_conv.hip timing experiments; 0 in the product): bit 0 = weights loaded once,
 //   bit 1 = input tile staged once.
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int PR, int PC, int OUT_MODE, int KNOCK = 0>
-__global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_ns_kernel(
+// MINB = workgroups per CU the register allocation must allow (3 where the accumulators leave room), PAD = padded LDS rows
+template <int CIN, int COUT, int PR, int PC, int OUT_MODE, int KNOCK = 0, int MINB = 2, bool PAD = true>
+__global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpb, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp, float2* __restrict__ stats) {
     constexpr int WN = COUT / 32, WM = 4 / WN, MT = PR * PC / WM, CK = 16, PSB = 48;
     constexpr int GS = MT < 4 ? MT : 4;                     // patches per MFMA group (independent accumulators in flight)
     constexpr int TR = 8 * PR, TC = 4 * PC, TROWS = TR + 2, TCOLS = TC + 2;
-    constexpr int RSB = conv_bf16x6_row_bytes(PC);
+    constexpr int RSB = conv_bf16x6_row_bytes(PC, PAD);
     constexpr int PLANE = TROWS * RSB;
     constexpr int G = (CIN / 16) * 9;
     static_assert(COUT % 32 == 0 && WN <= 4 && 4 % WN == 0 && (PR * PC) % WM == 0 && MT % GS == 0 && CIN % CK == 0, "tile shape");

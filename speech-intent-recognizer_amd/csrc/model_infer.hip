@@ -146,6 +146,7 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     static const int conv_bf16 = getenv("SIR_CONV_BF16X6") ? atoi(getenv("SIR_CONV_BF16X6")) : 1;
     // GRU variant: 1 = paired workgroups with W_hh resident on chip (default), 0 = single workgroup streaming W_hh
     const int gru_variant = sir_gru_variant();
+    static const int occ = getenv("SIR_CONV_OCC") ? atoi(getenv("SIR_CONV_OCC")) : 1;   // A/B: 3-workgroup-per-CU conv configurations
     // ---- weight preparation -------------------------------------------------------------
     // skipped when the caller vouches (sir_model_set_weights_version) that the weights are the ones prepared
     // into this very workspace by the previous call
@@ -192,6 +193,10 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
         if (conv_bf16) {
             constexpr size_t lds = conv_bf16x6_lds_bytes(4, 2);
             if (sir_conv_ns())
+if (occ)
+            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 0, 0, 3, false>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), conv_bf16x6_lds_bytes(4, 2, false), st, a1,
+                               (const unsigned short*)wcb2, bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
+            else
             hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 0>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), lds, st, a1,
                                (const unsigned short*)wcb2, bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
             else
@@ -217,6 +222,10 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
         if (conv_bf16 && conv3_variant == 0) {
         constexpr size_t lds = conv_bf16x6_lds_bytes(2, 4);
         if (sir_conv_ns())
+if (occ)
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 1, 0, 3, true>), dim3((d.wp2 + 7) / 8, 1, B), dim3(256), conv_bf16x6_lds_bytes(2, 2), st, a2,
+                           (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)nullptr);
+        else
         hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 4, 1>), dim3((d.wp2 + 15) / 16, 1, B), dim3(256), lds, st, a2,
                            (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)nullptr);
         else

@@ -27,7 +27,7 @@ enum TrainBuf {
 struct TDims {
     int B, T, wp1, wp2, wp3, S;
     int c1gx, c1gy;          // conv1 grids (ceil over un-pooled odd columns)
-    int c2gx, c3gx;
+    int c2gx, c3gx, c3fx;      // c3fx: conv3 FORWARD grid (16x8-pixel tiles); c3gx: conv3 data-gradient grid (16x16)
     int wg2_blocks, wg3_blocks, wg2_rb, wg3_rb;
     int ksplits, kchunk;
 };
@@ -40,6 +40,7 @@ bool make_tdims(int batch, int t, TDims* d) {
     d->c1gy = (32 + C1_PROWS - 1) / C1_PROWS;
     d->c2gx = (d->wp1 + 7) / 8;
     d->c3gx = (d->wp2 + 15) / 16;
+    d->c3fx = (d->wp2 + 7) / 8;
     d->wg2_rb = 16; d->wg3_rb = 8;                     // rows per workgroup of the weight-gradient kernels
     d->wg2_blocks = batch * (32 / d->wg2_rb);
     d->wg3_blocks = batch * (16 / d->wg3_rb);
@@ -66,7 +67,7 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     n[TB_BN] = 4 * 224;
     n[TB_BNB] = 2 * 224;
     size_t st = (size_t)d.c1gx * d.c1gy * B * 32;                       // conv1 partials (float2)
-    const size_t s2 = (size_t)d.c2gx * B * 64, s3 = (size_t)d.c3gx * B * 128;
+    const size_t s2 = (size_t)d.c2gx * B * 64, s3 = (size_t)d.c3fx * B * 128;
     if (s2 > st) st = s2;
     if (s3 > st) st = s3;
     const size_t bw = (size_t)(B * 16 * d.wp1 / 64 + 64) * 128;          // bn backward partials, generous
@@ -218,7 +219,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     {
         constexpr size_t lds = conv_bf16x6_lds_bytes(4, 2);
         if (sir_conv_ns())
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 2>), dim3(d.c2gx, 1, B), dim3(256), lds, st, (const float*)p.a1,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 2, 0, 3, false>), dim3(d.c2gx, 1, B), dim3(256), conv_bf16x6_lds_bytes(4, 2, false), st, (const float*)p.a1,
                            (const unsigned short*)p.wcb2, (const float*)nullptr, (const float*)nullptr, p.z2, 32, d.wp1, 16, d.wp2, p.stats);
         else
         hipLaunchKernelGGL((conv3x3_bf16x6_kernel<32, 64, 4, 2, 2, 2>), dim3(d.c2gx, 1, B), dim3(256), lds, st, (const float*)p.a1,
@@ -232,12 +233,12 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     {
         constexpr size_t lds = conv_bf16x6_lds_bytes(2, 4);
         if (sir_conv_ns())
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 4, 2>), dim3(d.c3gx, 1, B), dim3(256), lds, st, (const float*)p.a2,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 2, 0, 3, true>), dim3(d.c3fx, 1, B), dim3(256), conv_bf16x6_lds_bytes(2, 2), st, (const float*)p.a2,
                            (const unsigned short*)p.wcb3, (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats);
         else
         hipLaunchKernelGGL((conv3x3_bf16x6_kernel<64, 128, 2, 4, 2, 2>), dim3(d.c3gx, 1, B), dim3(256), lds, st, (const float*)p.a2,
                            (const unsigned short*)p.wcb3, (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, d.c3gx * B, 128,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, (sir_conv_ns() ? d.c3fx : d.c3gx) * B, 128,
                            (double)B * 16 * d.wp2, w->bn_w[2], w->bn_b[2], bn_running_mean[2], bn_running_var[2], bn_momentum,
                            scale + 96, shift + 96, smean + 96, sinv + 96);
         hipLaunchKernelGGL(bn_relu_pool_kernel<true>, dim3(grid_for((size_t)B * 8 * d.wp3 * 32)), dim3(256), 0, st, p.z3,
@@ -390,7 +391,7 @@ extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, co
         hipLaunchKernelGGL(prep_conv_wT_bf16x3_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], p.wcb3t, 64, 128);
         constexpr size_t ldsd = conv_bf16x6_lds_bytes(2, 4);
         if (sir_conv_ns())
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<128, 64, 2, 4, 2>), dim3(d.c3gx, 1, B), dim3(256), ldsd, st, (const float*)p.dz3,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<128, 64, 2, 4, 2, 0, 3, true>), dim3(d.c3gx, 1, B), dim3(256), ldsd, st, (const float*)p.dz3,
                            (const unsigned short*)p.wcb3t, (const float*)nullptr, (const float*)nullptr, p.da2, 16, d.wp2, 8, d.wp3,
                            (float2*)nullptr);
         else
@@ -431,7 +432,7 @@ extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, co
         hipLaunchKernelGGL(prep_conv_wT_bf16x3_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], p.wcb2t, 32, 64);
         constexpr size_t ldsd = conv_bf16x6_lds_bytes(4, 2);
         if (sir_conv_ns())
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 32, 4, 2, 2>), dim3(d.c2gx, 1, B), dim3(256), ldsd, st, (const float*)p.dz2,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 32, 4, 2, 2, 0, 3, false>), dim3(d.c2gx, 1, B), dim3(256), conv_bf16x6_lds_bytes(4, 2, false), st, (const float*)p.dz2,
                            (const unsigned short*)p.wcb2t, (const float*)nullptr, (const float*)nullptr, p.da1, 32, d.wp1, 16, d.wp2,
                            (float2*)nullptr);
         else

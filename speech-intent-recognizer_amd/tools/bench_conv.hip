@@ -49,7 +49,7 @@ static void run(const char* name, int B, int H, int W) {
     const double gf = 2.0 * B * H * W * (double)COUT * CIN * 9 * 1e-9;
     CK_(hipMemset(o1, 0, nout * 4)); CK_(hipMemset(o2, 0, nout * 4));
     float t1 = time_us(st, reps, [&] {
-        hipLaunchKernelGGL((conv3x3_bf16x6_kernel<CIN, COUT, PR, PC, OUT_MODE, 2>), grid, dim3(256), lds, st, (const float*)dx, (const unsigned short*)wpb,
+        hipLaunchKernelGGL((conv3x3_bf16x6_kernel<CIN, COUT, PR, PC, OUT_MODE, (PR * PC) / 4>), grid, dim3(256), lds, st, (const float*)dx, (const unsigned short*)wpb,
                            (const float*)ds, (const float*)dt, o1, H, W, Hp, Wp, (float2*)nullptr); });
     float t2 = time_us(st, reps, [&] {
         hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 0>), grid, dim3(256), lds, st, (const float*)dx, (const unsigned short*)wpb,
@@ -71,12 +71,27 @@ static void run(const char* name, int B, int H, int W) {
     float t5 = time_us(st, reps, [&] {
         hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 3>), grid, dim3(256), lds, st, (const float*)dx, (const unsigned short*)wpb,
                            (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
+    float t6 = time_us(st, reps, [&] {
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 0, 3>), grid, dim3(256), lds, st, (const float*)dx, (const unsigned short*)wpb,
+                           (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
+    constexpr size_t lds_np = (size_t)3 * (8 * PR + 2) * (4 * PC + 2) * 48;
+    float t7 = time_us(st, reps, [&] {
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 0, 3, false>), grid, dim3(256), lds_np, st, (const float*)dx, (const unsigned short*)wpb,
+                           (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
+    if (PR * PC <= 4 || COUT <= 64) {
+        float t8 = time_us(st, reps, [&] {
+            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 0, 4, false>), grid, dim3(256), lds_np, st, (const float*)dx, (const unsigned short*)wpb,
+                               (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
+        printf("  gen2 with launch_bounds(256,4), unpadded rows: %.1f us\n", t8);
+    }
+    printf("  gen2 with launch_bounds(256,3): %.1f us (LDS %zu B);  + unpadded rows: %.1f us (LDS %zu B)\n", t6, lds, t7, lds_np);
     printf("  gen2 knock-outs (timing only): weights once %.1f us, tile staged once %.1f us, both %.1f us\n", t3, t4, t5);
     hipFree(dx); hipFree(dw); hipFree(ds); hipFree(dt); hipFree(o1); hipFree(o2); hipFree(wpb);
 }
 
 int main() {
     run<64, 128, 2, 4, 1>("conv3", 256, 16, 50);
+    run<64, 128, 2, 2, 1>("conv3, 16x8-pixel tile (4 patches per wave)", 256, 16, 50);
     run<32, 64, 4, 2, 0>("conv2", 256, 32, 100);
     run<128, 64, 2, 4, 2>("conv3 data gradient", 256, 16, 50);
     run<64, 32, 4, 2, 2>("conv2 data gradient", 256, 32, 100);
