@@ -23,7 +23,7 @@ NAME_MAP = [
     ("gemm_nt_bf16x6_v3_kernel", "gemm_ih"),
     ("conv3x3_bf16x6_kernel<32, 64", "conv2_mfma_bn_relu_pool"), ("conv3x3_bf16x6_kernel<64, 128", "conv3_mfma_bn_relu_pool"),
     ("conv3x3_mfma_kernel<32, 64", "conv2_mfma_bn_relu_pool"), ("conv3x3_mfma_kernel<64, 128", "conv3_mfma_bn_relu_pool"),
-    ("gemm_nt_bf16x6_kernel", "gemm_ih"), ("gemm_nt_bias_kernel", "gemm_ih"), ("gru_recurrence_kernel", "gru_recurrence"), ("gru_pair_kernel", "gru_recurrence"),
+    ("gemm_nt_bf16x6_kernel", "gemm_ih"), ("gemm_nt_bias_kernel", "gemm_ih"), ("gru_recurrence_kernel", "gru_recurrence"), ("gru_pair_kernel", "gru_recurrence"), ("gru_quad_kernel", "gru_recurrence"),
     ("attention_pool_kernel", "attention_pool_fc_argmax"),
 ]
 
