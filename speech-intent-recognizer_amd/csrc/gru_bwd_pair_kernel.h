@@ -1,0 +1,158 @@
+// Paired-workgroup GRU back-propagation through time (mirror of gru_pair_kernel for the backward pass).
+//
+// gru_bwd_kernel re-streams W_hh (786 KB per direction) from L2 at every step: 238 us per layer at batch 256.
+// Here, as in the forward pair kernel, TWO workgroups share 4 utterances of one direction and workgroup `half`
+// keeps the 384 gate rows of ITS 128 hidden units resident for all S steps (10/16 in registers, 6/16 in LDS) --
+// but laid out for the transposed product: thread (k pair, row part) holds W[row][k] and W[row][k + 128] for 96 of
+// the 384 own rows (two k per thread halve the LDS broadcast reads of dgh, which bound the first version).
+// Per step:
+//   1. thread (unit, utterance) does the gate-gradient arithmetic, stores the dgi/dgh rows and puts the three
+//      hidden-side gate gradients of its unit into LDS;
+//   2. every thread accumulates  sum_{own rows} W[row][k] * dgh[row]  for its two k and its row part (768 FMAs,
+//      dgh broadcast from LDS), the four row parts are summed with two DPP exchanges: a PARTIAL of
+//      (W_hh^T dgh)[k] over this half's rows, for all 256 k;
+//   3. the partials of the k that belong to the PEER's units travel as 8-byte {tag, value} granules (same
+//      recipe and buffer layout as gru_pair_kernel); the partials of the own k are completed with the peer's
+//      granules and become next step's carried dh.
+// No atomics, fixed summation order: bit-reproducible.  Bias-gradient partial sums as in gru_bwd_kernel.
+#pragma once
+#include "gru_pair_kernel.h"
+
+constexpr int GBP_G4 = 24;                     // groups of 4 own rows per row part (96 rows), for each of the thread's two k
+constexpr int GBP_REG1 = 6;                    // groups of the second k kept in registers (the first k: all 24) -> 120 VGPRs
+constexpr int GBP_LDS4 = GBP_G4 - GBP_REG1;    // groups of the second k kept in LDS (18 x 8 KB)
+constexpr size_t GBP_LDS_BYTES = ((size_t)GBP_LDS4 * GP_THREADS * 4 + GP_BW * 384 + GP_BW * GP_UH) * 4;
+
+__global__ __launch_bounds__(GP_THREADS) void gru_bwd_pair_kernel(
+    const float* __restrict__ dy, const float* __restrict__ gates, const float* __restrict__ y, const float* __restrict__ whh0,
+    const float* __restrict__ whh1, float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ bsum_i,
+    float* __restrict__ bsum_h, int B, int S, float* xbuf, unsigned int* status) {
+    extern __shared__ __attribute__((aligned(16))) float blds[];
+    gp_f4* wl4 = reinterpret_cast<gp_f4*>(blds);                          // [GBP_LDS4][threads] float4 (4 consecutive own rows)
+    float* gsh = blds + (size_t)GBP_LDS4 * GP_THREADS * 4;                // dgh of the own rows: [utterance][384]
+    float* dhs = gsh + GP_BW * 384;                                       // (W_hh^T dgh) of the own units: [utterance][128]
+    const int dir = blockIdx.y, pair = blockIdx.x >> 1, half = blockIdx.x & 1;
+    const int b0 = pair * GP_BW;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* __restrict__ whh = dir ? whh1 : whh0;
+    unsigned long long* xg = reinterpret_cast<unsigned long long*>(xbuf) + (size_t)(pair * 2 + dir) * 2 * 2 * GP_BW * GP_UH;
+
+    // ---- matvec role: k pair kp = 16 wave + lane / 4 (k0 = kp, k1 = kp + 128), row part rp = lane & 3 ----------
+    const int kp = (wv << 4) | (lane >> 2), rp = lane & 3;
+    gp_f4 wr0[GBP_G4], wr1[GBP_REG1];
+    {
+        auto grow = [&](int ro) { return (ro >> 7) * 256 + half * GP_UH + (ro & 127); };     // own row -> row of W_hh
+#pragma unroll
+        for (int i = 0; i < GBP_G4; ++i) {
+            const int ro = rp * 96 + 4 * i;
+            const float* w0 = whh + (size_t)grow(ro) * 256, *w1 = whh + (size_t)grow(ro + 1) * 256;
+            const float* w2 = whh + (size_t)grow(ro + 2) * 256, *w3 = whh + (size_t)grow(ro + 3) * 256;
+            gp_f4 a, c;
+            a.x = w0[kp]; a.y = w1[kp]; a.z = w2[kp]; a.w = w3[kp];
+            c.x = w0[kp + 128]; c.y = w1[kp + 128]; c.z = w2[kp + 128]; c.w = w3[kp + 128];
+            wr0[i] = a;
+            if (i < GBP_REG1) wr1[i < GBP_REG1 ? i : 0] = c;
+            else wl4[(size_t)(i - GBP_REG1) * GP_THREADS + tid] = c;
+        }
+    }
+    // ---- gate role: unit ul = tid & 127 of this half, utterance bq = tid >> 7 ----------------------------
+    const int ul = tid & 127, bq = tid >> 7, u = half * GP_UH + ul;
+    const bool bvalid = (b0 + bq) < B;
+    for (int i = tid; i < GP_BW * GP_UH; i += GP_THREADS) dhs[i] = 0.0f;
+    float dhz = 0.0f;
+    float sum_r = 0.f, sum_z = 0.f, sum_n = 0.f, sum_nr = 0.f;
+    __syncthreads();
+
+    // the six per-step inputs of the gate role are fetched one step ahead (their latency hides behind a whole step)
+    float in_r = 0.f, in_z = 0.f, in_n = 0.f, in_hn = 0.f, in_hp = 0.f, in_dy = 0.f;
+    auto fetch = [&](int it_) {
+        if (!bvalid || it_ >= S) return;
+        const int step_ = S - 1 - it_;
+        const int t_ = dir ? (S - 1 - step_) : step_;
+        const int tp_ = dir ? t_ + 1 : t_ - 1;
+        const size_t row_ = (size_t)(b0 + bq) * S + t_;
+        const float* gs = gates + (row_ * 2 + dir) * 1024;
+        in_r = gs[u]; in_z = gs[256 + u]; in_n = gs[512 + u]; in_hn = gs[768 + u];
+        in_hp = (step_ > 0) ? y[((size_t)(b0 + bq) * S + tp_) * 512 + dir * 256 + u] : 0.0f;
+        in_dy = dy[row_ * 512 + dir * 256 + u];
+    };
+    fetch(0);
+    for (int it = 0; it < S; ++it) {
+        const int step = S - 1 - it;
+        const int t = dir ? (S - 1 - step) : step;                // time index processed now
+        float drp = 0.f, dzp = 0.f, dnp = 0.f, dnr = 0.f, dhz_new = 0.f;
+        const float r = in_r, zg = in_z, nn = in_n, hn = in_hn, hprev = in_hp, dyv = in_dy;
+        fetch(it + 1);
+        if (bvalid) {
+            const size_t row = (size_t)(b0 + bq) * S + t;
+            const float dh = dyv + dhz + dhs[bq * GP_UH + ul];
+            const float dn = dh * (1.0f - zg);
+            const float dz = dh * (hprev - nn);
+            dnp = dn * (1.0f - nn * nn);
+            drp = dnp * hn * r * (1.0f - r);
+            dzp = dz * zg * (1.0f - zg);
+            dnr = dnp * r;
+            dhz_new = dh * zg;
+            float* gi_o = dgi + row * 1536 + dir * 768;
+            float* gh_o = dgh + row * 1536 + dir * 768;
+            gi_o[u] = drp; gi_o[256 + u] = dzp; gi_o[512 + u] = dnp;
+            gh_o[u] = drp; gh_o[256 + u] = dzp; gh_o[512 + u] = dnr;
+            sum_r += drp; sum_z += dzp; sum_n += dnp; sum_nr += dnr;
+        }
+        dhz = dhz_new;
+        gsh[bq * 384 + ul] = drp; gsh[bq * 384 + 128 + ul] = dzp; gsh[bq * 384 + 256 + ul] = dnr;
+        __syncthreads();                                          // gsh complete; everyone has consumed dhs
+
+        // ---- partial of W_hh^T dgh over the own rows ----------------------------------------------------
+        float acc0[GP_BW], acc1[GP_BW];
+#pragma unroll
+        for (int bb = 0; bb < GP_BW; ++bb) { acc0[bb] = 0.0f; acc1[bb] = 0.0f; }
+        const float* gpart = gsh + rp * 96;
+        auto fma8 = [&](const gp_f4& a, const gp_f4& c, int i) {
+#pragma unroll
+            for (int bb = 0; bb < GP_BW; ++bb) {
+                const gp_f4 g4 = *reinterpret_cast<const gp_f4*>(gpart + bb * 384 + 4 * i);
+                acc0[bb] = fmaf(a.x, g4.x, acc0[bb]); acc0[bb] = fmaf(a.y, g4.y, acc0[bb]);
+                acc0[bb] = fmaf(a.z, g4.z, acc0[bb]); acc0[bb] = fmaf(a.w, g4.w, acc0[bb]);
+                acc1[bb] = fmaf(c.x, g4.x, acc1[bb]); acc1[bb] = fmaf(c.y, g4.y, acc1[bb]);
+                acc1[bb] = fmaf(c.z, g4.z, acc1[bb]); acc1[bb] = fmaf(c.w, g4.w, acc1[bb]);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < GBP_REG1; ++i) fma8(wr0[i], wr1[i], i);
+        asm volatile("" ::: "memory");                            // keep the LDS-resident weights in LDS
+#pragma unroll
+        for (int i = GBP_REG1; i < GBP_G4; ++i) fma8(wr0[i], wl4[(size_t)(i - GBP_REG1) * GP_THREADS + tid], i);
+#pragma unroll
+        for (int bb = 0; bb < GP_BW; ++bb) {                      // the four row parts: lanes 4j .. 4j + 3
+            acc0[bb] += gp_quad_xor1(acc0[bb]); acc0[bb] += gp_quad_xor2(acc0[bb]);
+            acc1[bb] += gp_quad_xor1(acc1[bb]); acc1[bb] += gp_quad_xor2(acc1[bb]);
+        }
+        // lane rp finishes utterance rp: one value for the own unit kp (k = kp + 128 half), one for the peer's
+        float s0 = acc0[0], s1 = acc1[0];
+#pragma unroll
+        for (int bb = 1; bb < GP_BW; ++bb) { s0 = (rp == bb) ? acc0[bb] : s0; s1 = (rp == bb) ? acc1[bb] : s1; }
+        const float vown = half ? s1 : s0, vpeer = half ? s0 : s1;
+        const unsigned tagv = (unsigned)(it + 1);
+        if (it + 1 < S) {
+            unsigned long long* gslot = xg + ((size_t)(it & 1) * 2 + half) * GP_BW * GP_UH;
+            const unsigned long long* gpeer = xg + ((size_t)(it & 1) * 2 + (half ^ 1)) * GP_BW * GP_UH;
+            __hip_atomic_store(gslot + rp * GP_UH + kp, ((unsigned long long)tagv << 32) | __float_as_uint(vpeer), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long pv;
+            unsigned spins = 0;
+            while ((unsigned)((pv = __hip_atomic_load(gpeer + rp * GP_UH + kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tagv) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > GP_SPIN_LIMIT) { __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            dhs[rp * GP_UH + kp] = vown + __uint_as_float((unsigned)pv);     // (dhs was last read before the barrier above)
+        }
+        __syncthreads();                                          // dhs of the next step complete
+    }
+    if (bvalid) {
+        float* bi = bsum_i + (size_t)(b0 + bq) * 1536 + dir * 768;
+        float* bh = bsum_h + (size_t)(b0 + bq) * 1536 + dir * 768;
+        bi[u] = sum_r; bi[256 + u] = sum_z; bi[512 + u] = sum_n;
+        bh[u] = sum_r; bh[256 + u] = sum_z; bh[512 + u] = sum_nr;
+    }
+}

@@ -3,6 +3,7 @@
 // whose register-pair constraints cost ~180 spilled VGPRs in this register-resident kernel.
 #include <stdlib.h>
 #include "gru_pair_kernel.h"
+#include "gru_bwd_pair_kernel.h"
 
 // exchange-granule workspace shared by the pair and the quad kernels: the larger of the two
 size_t sir_gru_pair_xbuf_bytes(int batch) {
@@ -31,6 +32,22 @@ int sir_launch_gru_pair(hipStream_t st, bool save, const float* gi, const float*
     else
         hipLaunchKernelGGL(gru_pair_kernel<false>, grid, dim3(GP_THREADS), GP_LDS_BYTES, st, gi, whh0, whh1, bhh0, bhh1, y, B, S, gates,
                            xbuf, flags, status, nowait);
+    SIR_HIP_TRY(hipGetLastError());
+    return SIR_OK;
+}
+
+int sir_launch_gru_bwd_pair(hipStream_t st, const float* dy, const float* gates, const float* y, const float* whh0, const float* whh1,
+                            float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S, float* xbuf, unsigned int* flags) {
+    static bool attr = false;
+    if (!attr) {
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_bwd_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GBP_LDS_BYTES));
+        attr = true;
+    }
+    const size_t npairs = (B + GP_BW - 1) / GP_BW;
+    unsigned int* status = flags + npairs * 2 * 2;
+    SIR_HIP_TRY(hipMemsetAsync(xbuf, 0, npairs * 2 * 2 * 2 * GP_BW * GP_UH * 8, st));     // tags are re-armed before every launch
+    hipLaunchKernelGGL(gru_bwd_pair_kernel, dim3((unsigned)(npairs * 2), 2), dim3(GP_THREADS), GBP_LDS_BYTES, st, dy, gates, y, whh0, whh1, dgi,
+                       dgh, bsum_i, bsum_h, B, S, xbuf, status);
     SIR_HIP_TRY(hipGetLastError());
     return SIR_OK;
 }

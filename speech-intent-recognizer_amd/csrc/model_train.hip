@@ -335,13 +335,17 @@ extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, co
         const float* yout = layer ? p.y1 : p.y0;
         const float* xin = layer ? y0in : p.x0;
         const int in_sz = layer ? 512 : 1024;
+static const int gru_bwd_variant = getenv("SIR_GRU_BWD_VARIANT") ? atoi(getenv("SIR_GRU_BWD_VARIANT")) : 1;
+        if (gru_bwd_variant == 1) {
+            rc = sir_launch_gru_bwd_pair(st, dy, gates, yout, w->gru_w_hh[2 * layer], w->gru_w_hh[2 * layer + 1], p.dgi, p.dgh, bsum_i, bsum_h,
+                                         B, S, p.gxb, p.gfl);
+            if (rc != SIR_OK) return rc;
+        } else
         hipLaunchKernelGGL(gru_bwd_kernel, dim3((B + GRU_BBW - 1) / GRU_BBW, 2), dim3(1024), 0, st, dy, gates, yout, (const float*)(p.wr4 + (size_t)2 * layer * 768 * 256),
                            p.dgi, p.dgh, bsum_i, bsum_h, B, S);
-        for (int dir = 0; dir < 2; ++dir) {      // bias gradients first: bsum_* alias the slab area used below
-            const int gi_idx = 2 * layer + dir;
-            hipLaunchKernelGGL(colsum_kernel, dim3(12), dim3(256), 0, st, (const float*)(bsum_i + dir * 768), B, 1536, 768, g->gru_b_ih[gi_idx]);
-            hipLaunchKernelGGL(colsum_kernel, dim3(12), dim3(256), 0, st, (const float*)(bsum_h + dir * 768), B, 1536, 768, g->gru_b_hh[gi_idx]);
-        }
+        // bias gradients first: bsum_* alias the slab area used below
+        hipLaunchKernelGGL(gru_bias_colsum_kernel, dim3(24, 2), dim3(256), 0, st, (const float*)bsum_i, (const float*)bsum_h, B,
+                           g->gru_b_ih[2 * layer], g->gru_b_ih[2 * layer + 1], g->gru_b_hh[2 * layer], g->gru_b_hh[2 * layer + 1]);
         for (int dir = 0; dir < 2; ++dir) {
             const int gi_idx = 2 * layer + dir;
             launch_tn(st, d, p.dgi + dir * 768, 1536, xin, in_sz, g->gru_w_ih[gi_idx], p.slab, 768, in_sz, M, 0, 0);

@@ -107,5 +107,8 @@ size_t sir_gru_quad_xbuf_bytes(int batch);
 int sir_launch_gru_quad(hipStream_t st, bool save, const float* gi, const float* whh0, const float* whh1, const float* bhh0,
                         const float* bhh1, float* y, int B, int S, float* gates, float* xbuf, unsigned int* status);
 int sir_gru_variant();
+// paired-workgroup GRU backward recurrence (gru_pair.hip); SIR_GRU_BWD_VARIANT=0 selects the streaming kernel
+int sir_launch_gru_bwd_pair(hipStream_t st, const float* dy, const float* gates, const float* y, const float* whh0, const float* whh1,
+                            float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S, float* xbuf, unsigned int* flags);
 // convolution generation (SIR_CONV_NS, default 1 = output channels split over the waves)
 int sir_conv_ns();

@@ -265,6 +265,26 @@ static __global__ __launch_bounds__(256) void colsum_kernel(const float* __restr
     if (part == 0 && col < n_cols) out[col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// the four GRU bias gradients of one layer in ONE launch: column sums of bsum_i / bsum_h [rows][1536] (blockIdx.y selects
+// the array), columns [0, 768) -> direction 0, [768, 1536) -> direction 1
+static __global__ __launch_bounds__(256) void gru_bias_colsum_kernel(const float* __restrict__ bsum_i, const float* __restrict__ bsum_h, int rows,
+                                                                      float* __restrict__ bi0, float* __restrict__ bi1,
+                                                                      float* __restrict__ bh0, float* __restrict__ bh1) {
+    __shared__ float red[4][64];
+    const float* in = blockIdx.y ? bsum_h : bsum_i;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;     // col < 1536 (grid.x = 24)
+    float a = 0.0f;
+#pragma unroll 8
+    for (int r = part; r < rows; r += 4) a += in[(size_t)r * 1536 + col];
+    red[part][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (part == 0) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        float* out = blockIdx.y ? (col < 768 ? bh0 : bh1) : (col < 768 ? bi0 : bi1);
+        out[col < 768 ? col : col - 768] = v;
+    }
+}
+
 // first stage for tall inputs: out[chunk][n] = sum over the rows of chunk `blockIdx.y` (then colsum_kernel)
 static __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ in, int rows, int ld, int n_cols,
                                                                      float* __restrict__ out) {
