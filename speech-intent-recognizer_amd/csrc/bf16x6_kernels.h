@@ -713,9 +713,22 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
             for (int q = 0; q < 4; ++q)
                 if (PYb + q < Hp) out[(((size_t)b * Hp + PYb + q) * Wp + PX) * COUT + co] = pooled[q];
         } else {
-            float* o = out + ((size_t)b * Wp + PX) * (COUT * Hp) + (size_t)co * Hp + PYb;
+            const size_t oidx = ((size_t)b * Wp + PX) * (COUT * Hp) + (size_t)co * Hp + PYb;
+            float* o = out + oidx;
             if ((Hp & 3) == 0) {
-                *reinterpret_cast<float4*>(o) = make_float4(pooled[0], pooled[1], pooled[2], pooled[3]);
+                const float4 v4 = make_float4(pooled[0], pooled[1], pooled[2], pooled[3]);
+                *reinterpret_cast<float4*>(o) = v4;
+                if (stats) {
+                    // OUT_MODE 1 only: `stats` carries the bf16x3 plane buffer [3][B * Wp][COUT * Hp] of the following
+                    // GEMM's A operand, written here so that no separate split pass has to re-read the activations
+                    unsigned short* planes = reinterpret_cast<unsigned short*>(stats);
+                    const size_t plane = (size_t)gridDim.z * Wp * (COUT * Hp);
+                    uint2 hh, mm, ll;
+                    split3_quad(v4, hh, mm, ll);
+                    *reinterpret_cast<uint2*>(planes + oidx) = hh;
+                    *reinterpret_cast<uint2*>(planes + plane + oidx) = mm;
+                    *reinterpret_cast<uint2*>(planes + 2 * plane + oidx) = ll;
+                }
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)

@@ -49,7 +49,8 @@ template <bool SAVE>
 __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     const float* __restrict__ gi, const float* __restrict__ whh0, const float* __restrict__ whh1,
     const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ y, int B, int S,
-    float* __restrict__ gates, unsigned long long* xbuf, unsigned int* status, int dbg = 0) {
+    float* __restrict__ gates, unsigned long long* xbuf, unsigned int* status, int dbg, unsigned short* __restrict__ yplanes) {
+    // yplanes (optional): bf16x3 planes [3][B * S][512] of y, the A operand of the next layer's input projection
     // dbg (timing experiments only, results invalid): bit 0 = do not wait for the granules, bit 1 = skip the MFMAs,
     // bit 2 = skip publish + receive
     extern __shared__ __attribute__((aligned(16))) unsigned char qlds[];
@@ -175,7 +176,14 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (bvalid) {
-            *reinterpret_cast<float4*>(y + ((size_t)b * S + t) * 512 + dir * 256 + u0) = hprev;
+            const size_t yidx = ((size_t)b * S + t) * 512 + dir * 256 + u0;
+            *reinterpret_cast<float4*>(y + yidx) = hprev;
+            if (yplanes) {
+                const size_t plane = (size_t)B * S * 512;
+                *reinterpret_cast<uint2*>(yplanes + yidx) = ph;
+                *reinterpret_cast<uint2*>(yplanes + plane + yidx) = pm;
+                *reinterpret_cast<uint2*>(yplanes + 2 * plane + yidx) = pl;
+            }
             if (SAVE) {
                 float* gsv = gates + (((size_t)b * S + t) * 2 + dir) * 1024 + u0;
                 *reinterpret_cast<float4*>(gsv) = make_float4(r4[0], r4[1], r4[2], r4[3]);

@@ -147,6 +147,11 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     // GRU variant: 1 = paired workgroups with W_hh resident on chip (default), 0 = single workgroup streaming W_hh
     const int gru_variant = sir_gru_variant();
     static const int occ = getenv("SIR_CONV_OCC") ? atoi(getenv("SIR_CONV_OCC")) : 1;   // A/B: 3-workgroup-per-CU conv configurations
+    // producers write the bf16x3 planes of the next GEMM's A operand themselves (conv3 -> projection 0, GRU layer 0 ->
+    // projection 1) instead of a separate split pass over the fp32 activations
+    static const int fuse_env = getenv("SIR_FUSE_SPLIT") ? atoi(getenv("SIR_FUSE_SPLIT")) : 1;
+    const bool fuse_x0 = fuse_env && conv_bf16 && occ && sir_conv_ns() && gemm_variant == 2;
+    const bool fuse_y0 = fuse_env && gru_variant == 2 && gemm_variant == 2;
     // ---- weight preparation -------------------------------------------------------------
     // skipped when the caller vouches (sir_model_set_weights_version) that the weights are the ones prepared
     // into this very workspace by the previous call
@@ -224,7 +229,7 @@ if (occ)
         if (sir_conv_ns())
 if (occ)
         hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 1, 0, 3, true>), dim3((d.wp2 + 7) / 8, 1, B), dim3(256), conv_bf16x6_lds_bytes(2, 2), st, a2,
-                           (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)nullptr);
+                           (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, fuse_x0 ? (float2*)xs : (float2*)nullptr);
         else
         hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 4, 1>), dim3((d.wp2 + 15) / 16, 1, B), dim3(256), lds, st, a2,
                            (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)nullptr);
@@ -258,7 +263,7 @@ if (occ)
     }
     { SirProfScope prof(h, SIR_K_GEMM_IH0, st);
     if (gemm_variant == 2) {
-        hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, (const float*)x0, 1024, xs, (size_t)M, 1024);
+        if (!fuse_x0) hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, (const float*)x0, 1024, xs, (size_t)M, 1024);
         SIR_HIP_TRY(launch_gemm_nt_bf16x6(st, sir_gemm_bf16x6_gen(), (const unsigned short*)xs, (const unsigned short*)wsl0,
                            (const unsigned short*)(wsl0 + (size_t)3 * 768 * 1024), w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024));
     } else if (gemm_variant == 1)
@@ -269,7 +274,8 @@ if (occ)
                        w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024); }
     { SirProfScope prof(h, SIR_K_GRU0, st);
     if (gru_variant == 2) {
-        const int rc = sir_launch_gru_quad(st, false, gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S, nullptr, gxb, gfl);
+        const int rc = sir_launch_gru_quad(st, false, gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S, nullptr, gxb, gfl,
+                                           fuse_y0 ? xs : nullptr);
         if (rc != SIR_OK) return rc;
     } else if (gru_variant == 1) {
         const int rc = sir_launch_gru_pair(st, false, gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S, nullptr, gxb, gfl);
@@ -279,7 +285,7 @@ if (occ)
                        (float*)nullptr); }
     { SirProfScope prof(h, SIR_K_GEMM_IH1, st);
     if (gemm_variant == 2) {
-        hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, (const float*)y0, 512, xs, (size_t)M, 512);
+        if (!fuse_y0) hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, (const float*)y0, 512, xs, (size_t)M, 512);
         SIR_HIP_TRY(launch_gemm_nt_bf16x6(st, sir_gemm_bf16x6_gen(), (const unsigned short*)xs, (const unsigned short*)wsl1,
                            (const unsigned short*)(wsl1 + (size_t)3 * 768 * 512), w->gru_b_ih[2], w->gru_b_ih[3], gi, 1536, M, 768, 512));
     } else

@@ -251,7 +251,9 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, (const float*)p.x0, 1024, p.xs, (size_t)M, 1024);
     SIR_HIP_TRY(launch_gemm_nt_bf16x6(st, sir_gemm_bf16x6_gen(), (const unsigned short*)p.xs, (const unsigned short*)p.wsl0,
                        (const unsigned short*)(p.wsl0 + (size_t)3 * 768 * 1024), w->gru_b_ih[0], w->gru_b_ih[1], p.gi, 1536, M, 768, 1024));
-    rc = (sir_gru_variant() == 2 ? sir_launch_gru_quad : sir_launch_gru_pair)(st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0, p.gxb, p.gfl);
+    rc = sir_gru_variant() == 2
+             ? sir_launch_gru_quad(st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0, p.gxb, p.gfl)
+             : sir_launch_gru_pair(st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0, p.gxb, p.gfl);
     if (rc != SIR_OK) return rc;
     const float* y0in = p.y0;
     if (dropout_p > 0.0f) {
@@ -262,7 +264,9 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, y0in, 512, p.xs, (size_t)M, 512);
     SIR_HIP_TRY(launch_gemm_nt_bf16x6(st, sir_gemm_bf16x6_gen(), (const unsigned short*)p.xs, (const unsigned short*)p.wsl1,
                        (const unsigned short*)(p.wsl1 + (size_t)3 * 768 * 512), w->gru_b_ih[2], w->gru_b_ih[3], p.gi, 1536, M, 768, 512));
-    rc = (sir_gru_variant() == 2 ? sir_launch_gru_quad : sir_launch_gru_pair)(st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1, p.gxb, p.gfl);
+    rc = sir_gru_variant() == 2
+             ? sir_launch_gru_quad(st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1, p.gxb, p.gfl)
+             : sir_launch_gru_pair(st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1, p.gxb, p.gfl);
     if (rc != SIR_OK) return rc;
     hipLaunchKernelGGL(attention_pool_kernel, dim3(B), dim3(256), 0, st, p.y1, w->attn_w, w->attn_b, p.ctx, S, w->fc_w,
                        w->fc_b, w->num_classes, logits, (long long*)nullptr);

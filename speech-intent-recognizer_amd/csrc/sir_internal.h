@@ -105,7 +105,8 @@ int sir_gemm_bf16x6_gen();
 // quad-workgroup MFMA GRU recurrence (gru_quad.hip); SIR_GRU_VARIANT=2 selects it
 size_t sir_gru_quad_xbuf_bytes(int batch);
 int sir_launch_gru_quad(hipStream_t st, bool save, const float* gi, const float* whh0, const float* whh1, const float* bhh0,
-                        const float* bhh1, float* y, int B, int S, float* gates, float* xbuf, unsigned int* status);
+                        const float* bhh1, float* y, int B, int S, float* gates, float* xbuf, unsigned int* status,
+                        unsigned short* yplanes = nullptr);
 int sir_gru_variant();
 // paired-workgroup GRU backward recurrence (gru_pair.hip); SIR_GRU_BWD_VARIANT=0 selects the streaming kernel
 int sir_launch_gru_bwd_pair(hipStream_t st, const float* dy, const float* gates, const float* y, const float* whh0, const float* whh1,
