@@ -108,7 +108,6 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     for (int step = 0; step < S; ++step) {
         const int t = dir ? (S - 1 - step) : step;
         float4 gcur[3] = {gin[0], gin[1], gin[2]};
-        if (step + 1 < S) load_gi(dir ? (S - 2 - step) : step + 1, gin);
         const unsigned char* hb = qlds + (step & 1) * GQ_BUFB;
         unsigned char* hnb = qlds + ((step + 1) & 1) * GQ_BUFB;
 
@@ -175,24 +174,6 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
                 __hip_atomic_store(gs + j, tag | ((unsigned long long)hh_[j] << 32) | ((unsigned long long)mm_[j] << 16) | ll_[j],
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (bvalid) {
-            const size_t yidx = ((size_t)b * S + t) * 512 + dir * 256 + u0;
-            *reinterpret_cast<float4*>(y + yidx) = hprev;
-            if (yplanes) {
-                const size_t plane = (size_t)B * S * 512;
-                *reinterpret_cast<uint2*>(yplanes + yidx) = ph;
-                *reinterpret_cast<uint2*>(yplanes + plane + yidx) = pm;
-                *reinterpret_cast<uint2*>(yplanes + 2 * plane + yidx) = pl;
-            }
-            if (SAVE) {
-                float* gsv = gates + (((size_t)b * S + t) * 2 + dir) * 1024 + u0;
-                *reinterpret_cast<float4*>(gsv) = make_float4(r4[0], r4[1], r4[2], r4[3]);
-                *reinterpret_cast<float4*>(gsv + 256) = make_float4(z4[0], z4[1], z4[2], z4[3]);
-                *reinterpret_cast<float4*>(gsv + 512) = make_float4(n4[0], n4[1], n4[2], n4[3]);
-                *reinterpret_cast<float4*>(gsv + 768) = make_float4(hh4[0], hh4[1], hh4[2], hh4[3]);
-            }
-        }
-
         // ---- receive the other three quarters' values of this step into the next-parity planes ------------
         if (step + 1 < S && !(dbg & 4)) {
             // all 12 granule loads of a poll round are independent (issued back to back, one wait); a round is
@@ -234,6 +215,27 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
                 *reinterpret_cast<uint2*>(d + 2 * GQ_PLANEB) = rl;
             }
         }
+        // the stores of this step and the loads of the next one are issued only now: a hand-off costs what sits in the
+        // CONSUMER CU's memory queue ahead of the poll (MI355X_MICROARCH.md, handoff-1to1: 0.8 us idle, 2.5-2.9 loaded)
+        if (bvalid) {
+            const size_t yidx = ((size_t)b * S + t) * 512 + dir * 256 + u0;
+            *reinterpret_cast<float4*>(y + yidx) = hprev;
+            if (yplanes) {
+                const size_t plane = (size_t)B * S * 512;
+                *reinterpret_cast<uint2*>(yplanes + yidx) = ph;
+                *reinterpret_cast<uint2*>(yplanes + plane + yidx) = pm;
+                *reinterpret_cast<uint2*>(yplanes + 2 * plane + yidx) = pl;
+            }
+            if (SAVE) {
+                float* gsv = gates + (((size_t)b * S + t) * 2 + dir) * 1024 + u0;
+                *reinterpret_cast<float4*>(gsv) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+                *reinterpret_cast<float4*>(gsv + 256) = make_float4(z4[0], z4[1], z4[2], z4[3]);
+                *reinterpret_cast<float4*>(gsv + 512) = make_float4(n4[0], n4[1], n4[2], n4[3]);
+                *reinterpret_cast<float4*>(gsv + 768) = make_float4(hh4[0], hh4[1], hh4[2], hh4[3]);
+            }
+        }
+
+        if (step + 1 < S) load_gi(dir ? (S - 2 - step) : step + 1, gin);
         __syncthreads();                                     // next-parity planes complete; this parity's reads are done
     }
 }
