@@ -12,5 +12,5 @@ tail -2 gpurun_out/smoke.log
 timeout -k 10 600 python bench.py --steps ${STEPS:-100} --warmup 20 > gpurun_out/bench.log 2> gpurun_out/bench.err || { tail -20 gpurun_out/bench.err; exit 1; }
 cat gpurun_out/bench.log
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o infer -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof.log 2>&1 || { tail -20 $R/gpurun_out/prof.log; exit 1; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o infer -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --streams 1 > $R/gpurun_out/prof.log 2>&1 || { tail -20 $R/gpurun_out/prof.log; exit 1; }
 ls -R $R/gpurun_out/prof | head -20
