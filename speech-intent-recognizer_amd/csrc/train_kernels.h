@@ -834,6 +834,9 @@ static __global__ void prep_conv_wT_kernel(const float* __restrict__ w, float* _
 //   read with conflict-free ds_read_b32 (32 consecutive channels).  Per-workgroup partial
 //   gradients go to slab[blk][tap][co][ci] and are summed (and transposed to the torch layout) by
 //   wgrad_reduce_kernel: deterministic, no atomics.
+//   (Tried: dealing the 9 * MT * NT tiles of a k step evenly to 8 / 4 waves instead of wave = tap, to balance the
+//   SIMDs -- 9 waves put three on one SIMD.  Correct but 10 % slower: one more ds_read_b32 per MFMA; the kernel is
+//   bound by its LDS operand reads, not by the matrix pipes.)
 // ------------------------------------------------------------------------------------------
 template <int CIN, int COUT>
 __global__ __launch_bounds__(576) void conv_wgrad_mfma_kernel(const float* __restrict__ dz, const float* __restrict__ a,
