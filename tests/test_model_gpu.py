@@ -121,3 +121,16 @@ def test_batch_pipeline_matches_single_stream(sd):
     pipe.synchronize()
     for (l0, a0), (l1, a1) in zip(ref, outs):
         assert torch.equal(l0, l1) and torch.equal(a0, a1)
+
+
+@pytest.mark.parametrize("bsz,t", [(37, 120), (17, 8), (3, 333), (130, 64)])
+def test_ragged_shapes_vs_oracle(sd, bsz, t):
+    """Batch sizes that do not fill the kernels' utterance groups (16 per GRU cluster, 4 per pair) and frame counts that
+    do not fill the pixel tiles: logits within 2e-5 of the oracle, argmax identical."""
+    x = cases.varied_features(bsz, t, seed=1000 + bsz)
+    m = _model(sd)
+    logits, amax = m.predict(x.to(DEV))
+    with torch.no_grad():
+        ref = model_ref.forward(sd, x)
+    assert (logits.cpu() - ref).abs().max() <= 2e-5
+    assert torch.equal(amax.cpu(), ref.argmax(1))
