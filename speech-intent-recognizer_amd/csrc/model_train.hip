@@ -4,6 +4,7 @@
 // train_epoch (scripts/train.py:90-107: forward, criterion, loss.backward(), optimizer.step()).
 #include "train_kernels.h"
 #include "bf16x6_kernels.h"
+#include "wgrad_bf16x6_kernel.h"
 
 namespace {
 
@@ -90,7 +91,7 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     n[TB_DA1] = n[TB_A1];
     n[TB_SMALL] = B * 512 + B + 64 + (size_t)d.c1gx * d.c1gy * B * 288;
     size_t slab = (size_t)d.wg3_blocks * 9 * 128 * 64;
-    const size_t s_w2 = (size_t)d.wg2_blocks * 9 * 64 * 32, s_g = (size_t)d.ksplits * 768 * 1024;
+    const size_t s_w2 = (size_t)d.wg2_blocks * wgrad_x6_ksplit(32, 64) * 9 * 64 * 32, s_g = (size_t)d.ksplits * 768 * 1024;
     if (s_w2 > slab) slab = s_w2;
     if (s_g > slab) slab = s_g;
     n[TB_SLAB] = slab + (size_t)WGR_PARTS * 9 * 128 * 64;       // + the partial sums of the two-pass wgrad reduce
@@ -387,12 +388,26 @@ static const int gru_bwd_variant = getenv("SIR_GRU_BWD_VARIANT") ? atoi(getenv("
             attr3 = true;
         }
         if (lds > 160 * 1024) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
+        static const int wgrad_x6 = getenv("SIR_WGRAD_X6") ? atoi(getenv("SIR_WGRAD_X6")) : 1;
+        int nslab3 = d.wg3_blocks;
+        if (wgrad_x6) {
+            static bool attrx = false;
+            if (!attrx) {
+                SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<64, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attrx = true;
+            }
+            const size_t ldsx = wgrad_x6_lds_bytes(64, 128, d.wp2);
+            if (ldsx > 160 * 1024 || d.wp2 > wgrad_x6_max_w(128)) { sir_set_error("sir_model_train_bwd: t_frames too large for the bf16x6 weight-gradient tile"); return SIR_EUNSUPPORTED; }
+            nslab3 = d.wg3_blocks * wgrad_x6_ksplit(64, 128);
+            hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<64, 128>), dim3(d.wg3_blocks), dim3(512), ldsx, st, (const float*)p.dz3,
+                               (const float*)p.a2, p.slab, 16, d.wp2, d.wg3_rb);
+        } else
         hipLaunchKernelGGL((conv_wgrad_mfma_kernel<64, 128>), dim3(d.wg3_blocks), dim3(576), lds, st, (const float*)p.dz3,
                            (const float*)p.a2, p.slab, 16, d.wp2, d.wg3_rb);
-{
-            float* part = p.slab + (size_t)d.wg3_blocks * 9 * 128 * 64;
+        {
+            float* part = p.slab + (size_t)nslab3 * 9 * 128 * 64;
             hipLaunchKernelGGL(wgrad_reduce_partial_kernel, dim3((9 * 128 * 64 / 4 + 255) / 256, WGR_PARTS), dim3(256), 0, st,
-                               (const float*)p.slab, d.wg3_blocks, 9 * 128 * 64 / 4, part);
+                               (const float*)p.slab, nslab3, 9 * 128 * 64 / 4, part);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 128 * 64 + 255) / 256), dim3(256), 0, st, (const float*)part, WGR_PARTS, 64, 128,
                                g->conv_w[2]);
         }
@@ -428,12 +443,26 @@ static const int gru_bwd_variant = getenv("SIR_GRU_BWD_VARIANT") ? atoi(getenv("
             attr2 = true;
         }
         if (lds > 160 * 1024) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
+        static const int wgrad_x6b = getenv("SIR_WGRAD_X6") ? atoi(getenv("SIR_WGRAD_X6")) : 1;
+        int nslab2 = d.wg2_blocks;
+        if (wgrad_x6b) {
+            static bool attrx2 = false;
+            if (!attrx2) {
+                SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attrx2 = true;
+            }
+            const size_t ldsx = wgrad_x6_lds_bytes(32, 64, d.wp1);
+            if (ldsx > 160 * 1024 || d.wp1 > wgrad_x6_max_w(64)) { sir_set_error("sir_model_train_bwd: t_frames too large for the bf16x6 weight-gradient tile"); return SIR_EUNSUPPORTED; }
+            nslab2 = d.wg2_blocks * wgrad_x6_ksplit(32, 64);
+            hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<32, 64>), dim3(d.wg2_blocks), dim3(512), ldsx, st, (const float*)p.dz2,
+                               (const float*)p.a1, p.slab, 32, d.wp1, d.wg2_rb);
+        } else
         hipLaunchKernelGGL((conv_wgrad_mfma_kernel<32, 64>), dim3(d.wg2_blocks), dim3(576), lds, st, (const float*)p.dz2,
                            (const float*)p.a1, p.slab, 32, d.wp1, d.wg2_rb);
-{
-            float* part = p.slab + (size_t)d.wg2_blocks * 9 * 64 * 32;
+        {
+            float* part = p.slab + (size_t)nslab2 * 9 * 64 * 32;
             hipLaunchKernelGGL(wgrad_reduce_partial_kernel, dim3((9 * 64 * 32 / 4 + 255) / 256, WGR_PARTS), dim3(256), 0, st,
-                               (const float*)p.slab, d.wg2_blocks, 9 * 64 * 32 / 4, part);
+                               (const float*)p.slab, nslab2, 9 * 64 * 32 / 4, part);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 32 + 255) / 256), dim3(256), 0, st, (const float*)part, WGR_PARTS, 32, 64,
                                g->conv_w[1]);
         }
