@@ -89,7 +89,7 @@ def host_cpu_share(cap=16):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc pass (profiles/*/pmc_traffic.json,
-    written by scripts_gpu_pmc.sh + tools in profiles/), or None when no measurement is on file."""
+    written by devtools/gpu_pmc.sh + tools in profiles/), or None when no measurement is on file."""
     try:
         import glob
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")))

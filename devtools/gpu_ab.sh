@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of one env switch inside one GPU-box session: ./scripts_gpu_ab.sh VAR val_a val_b
+# A/B of one env switch inside one GPU-box session: ./gpu_ab.sh VAR val_a val_b
 # (model/train parity tests under val_b first, then alternating inference-only bench runs)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}

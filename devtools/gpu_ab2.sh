@@ -1,5 +1,5 @@
 #!/bin/bash
-# like scripts_gpu_ab.sh but inference-only and single pass per value: ./scripts_gpu_ab2.sh VAR v1 v2 ...
+# like gpu_ab.sh but inference-only and single pass per value: devtools/gpu_ab2.sh VAR v1 v2 ...
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out

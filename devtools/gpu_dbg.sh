@@ -1,5 +1,5 @@
 #!/bin/bash
-# timing-only sweep of one debug env var (no parity tests): ./scripts_gpu_dbg.sh VAR v1 v2 ...
+# timing-only sweep of one debug env var (no parity tests): devtools/gpu_dbg.sh VAR v1 v2 ...
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
 VAR=$1; shift

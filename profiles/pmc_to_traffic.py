@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 --pmc passes of scripts_gpu_pmc.sh (FETCH_SIZE and WRITE_SIZE, collected in
+"""Turn the rocprofv3 --pmc passes of devtools/gpu_pmc.sh (FETCH_SIZE and WRITE_SIZE, collected in
 separate passes) into HBM bytes per launch for the kernels bench.py reports.
 
     python profiles/pmc_to_traffic.py gpurun_out/pmc profiles/r01
