@@ -5,7 +5,7 @@
 size_t sir_gru_quad_xbuf_bytes(int batch) { return (size_t)((batch + GQ_NU - 1) / GQ_NU) * 2 * GQ_XBUF_PER_CLUSTER; }
 
 int sir_launch_gru_quad(hipStream_t st, bool save, const float* gi, const float* whh0, const float* whh1, const float* bhh0,
-                        const float* bhh1, float* y, int B, int S, float* gates, float* xbuf, unsigned int* status, unsigned short* yplanes) {
+                        const float* bhh1, float* y, int B, int S, float* gates, float* xbuf, unsigned int* status, unsigned short* yplanes, const void* wfrag0, const void* wfrag1) {
     static bool attr = false;
     if (!attr) {
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_quad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GQ_LDS_BYTES));
@@ -19,10 +19,15 @@ int sir_launch_gru_quad(hipStream_t st, bool save, const float* gi, const float*
     static const int dbg = getenv("SIR_GRU_DBG") ? atoi(getenv("SIR_GRU_DBG")) : 0;
     if (save)
         hipLaunchKernelGGL(gru_quad_kernel<true>, grid, dim3(GQ_THREADS), GQ_LDS_BYTES, st, gi, whh0, whh1, bhh0, bhh1, y, B, S, gates,
-                           (unsigned long long*)xbuf, status, dbg, yplanes);
+                           (unsigned long long*)xbuf, status, dbg, yplanes, (const uint4*)wfrag0, (const uint4*)wfrag1);
     else
         hipLaunchKernelGGL(gru_quad_kernel<false>, grid, dim3(GQ_THREADS), GQ_LDS_BYTES, st, gi, whh0, whh1, bhh0, bhh1, y, B, S, gates,
-                           (unsigned long long*)xbuf, status, dbg, yplanes);
+                           (unsigned long long*)xbuf, status, dbg, yplanes, (const uint4*)wfrag0, (const uint4*)wfrag1);
     SIR_HIP_TRY(hipGetLastError());
     return SIR_OK;
+}
+
+// inference-side preparation of one direction's resident fragments (768 x 256 x 6 bytes)
+void sir_prep_whh_quad(hipStream_t st, const float* whh, void* frag) {
+    hipLaunchKernelGGL(prep_whh_quad_kernel, dim3(4 * 4 * 3 * 8 * 64 / 256), dim3(256), 0, st, whh, (uint4*)frag);
 }

@@ -43,13 +43,32 @@ __device__ __forceinline__ float gq_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x));
 }
 
+// W_hh of one direction as the kernel's resident MFMA fragments: [quarter][wave][gate][k-step][plane][lane] uint4
+// (inference prepares this once per weights version; the kernel prologue is then 72 coalesced 16-byte loads per lane
+// instead of 48 row-strided fp32 loads and the three-way split)
+static __global__ __launch_bounds__(256) void prep_whh_quad_kernel(const float* __restrict__ whh, uint4* __restrict__ frag) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;              // ((((q*4 + wv)*3 + g)*8 + s)*64 + lane)
+    if (idx >= 4 * 4 * 3 * 8 * 64) return;
+    const int lane = idx & 63, s = (idx >> 6) & 7, g = (idx >> 9) % 3, qw = idx / (64 * 8 * 3), wv = qw & 3, q = qw >> 2;
+    const float* wrow = whh + (size_t)(g * 256 + q * 64 + wv * 16 + (lane & 15)) * 256 + s * 32 + (lane >> 4) * 8;
+    uint2 h0, m0, l0, h1, m1, l1;
+    split3_quad(*reinterpret_cast<const float4*>(wrow), h0, m0, l0);
+    split3_quad(*reinterpret_cast<const float4*>(wrow + 4), h1, m1, l1);
+    uint4* o = frag + ((size_t)(((qw * 3 + g) * 8 + s) * 3) * 64 + lane);
+    o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    o[64] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+    o[128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
 // xbuf   [clusters][2 parity][4 quarters][16 utterances][64 units] 8-byte granules, zeroed before every launch
 // status set to 1 if a spin times out (results are then invalid; cannot happen while a cluster is co-resident)
 template <bool SAVE>
 __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     const float* __restrict__ gi, const float* __restrict__ whh0, const float* __restrict__ whh1,
     const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ y, int B, int S,
-    float* __restrict__ gates, unsigned long long* xbuf, unsigned int* status, int dbg, unsigned short* __restrict__ yplanes) {
+    float* __restrict__ gates, unsigned long long* xbuf, unsigned int* status, int dbg, unsigned short* __restrict__ yplanes,
+    const uint4* __restrict__ wfrag0, const uint4* __restrict__ wfrag1) {
+    // wfrag0/1 (optional): prep_whh_quad_kernel output for direction 0 / 1
     // yplanes (optional): bf16x3 planes [3][B * S][512] of y, the A operand of the next layer's input projection
     // dbg (timing experiments only, results invalid): bit 0 = do not wait for the granules, bit 1 = skip the MFMAs,
     // bit 2 = skip publish + receive
@@ -67,6 +86,16 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
 
     // ---- resident weights: A fragments of the three gate tiles, bf16x3 planes --------------------------
     bf16x8 wf[3][8][3];
+    const uint4* __restrict__ wfrag = dir ? wfrag1 : wfrag0;
+    if (wfrag) {
+        const uint4* wsrc = wfrag + (size_t)((q * 4 + wv) * 3 * 8 * 3) * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wf[g][s][p] = __builtin_bit_cast(bf16x8, wsrc[((g * 8 + s) * 3 + p) * 64]);
+    } else {
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
         const float* wrow = whh + (size_t)(g * 256 + q * GQ_UQ + wv * 16 + n) * 256 + kg * 8;   // A row = lane & 15
@@ -81,6 +110,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
             wf[g][s][1] = __builtin_bit_cast(bf16x8, make_uint4(m0.x, m0.y, m1.x, m1.y));
             wf[g][s][2] = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
         }
+    }
     }
     float4 bh[3];
 #pragma unroll

@@ -47,7 +47,7 @@ void ws_sizes(const Dims& d, size_t* bytes) {
     bytes[WS_WP2] = (size_t)36 * 64 * 8 * 4;
     bytes[WS_WP3] = (size_t)72 * 128 * 8 * 4;
     bytes[WS_BN] = (size_t)2 * 224 * 4;
-    bytes[WS_WHT] = (size_t)4 * 768 * 256 * 4;
+    bytes[WS_WHT] = (size_t)4 * 768 * 256 * 6;                  // streaming GRU: W_hh regrouped (fp32); quad GRU: resident bf16x3 fragments
     bytes[WS_XS] = B * d.S * 1024 * 3 * 2;
     bytes[WS_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512) * 2;
     bytes[WS_WCB] = ((size_t)3 * 32 * 9 * 64 + (size_t)3 * 64 * 9 * 128) * 2;
@@ -173,6 +173,8 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     if (gru_variant == 0)
         for (int i = 0; i < 4; ++i)
             hipLaunchKernelGGL(prep_whh_kernel, dim3(768), dim3(256), 0, st, w->gru_w_hh[i], wht + (size_t)i * 768 * 256);
+    if (gru_variant == 2)
+        for (int i = 0; i < 4; ++i) sir_prep_whh_quad(st, w->gru_w_hh[i], (unsigned char*)wht + (size_t)i * 768 * 256 * 6);
     if (conv_bf16) {
         hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], wcb2, 32, 64);
         hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], wcb3, 64, 128);
@@ -275,7 +277,7 @@ if (occ)
     { SirProfScope prof(h, SIR_K_GRU0, st);
     if (gru_variant == 2) {
         const int rc = sir_launch_gru_quad(st, false, gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S, nullptr, gxb, gfl,
-                                           fuse_y0 ? xs : nullptr);
+                                           fuse_y0 ? xs : nullptr, wht, (unsigned char*)wht + (size_t)768 * 256 * 6);
         if (rc != SIR_OK) return rc;
     } else if (gru_variant == 1) {
         const int rc = sir_launch_gru_pair(st, false, gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S, nullptr, gxb, gfl);
@@ -293,7 +295,8 @@ if (occ)
                        w->gru_b_ih[2], w->gru_b_ih[3], gi, 1536, M, 768, 512); }
     { SirProfScope prof(h, SIR_K_GRU1, st);
     if (gru_variant == 2) {
-        const int rc = sir_launch_gru_quad(st, false, gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], y1, B, S, nullptr, gxb, gfl);
+        const int rc = sir_launch_gru_quad(st, false, gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], y1, B, S, nullptr, gxb, gfl,
+                                           nullptr, (unsigned char*)wht + (size_t)2 * 768 * 256 * 6, (unsigned char*)wht + (size_t)3 * 768 * 256 * 6);
         if (rc != SIR_OK) return rc;
     } else if (gru_variant == 1) {
         const int rc = sir_launch_gru_pair(st, false, gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], y1, B, S, nullptr, gxb, gfl);

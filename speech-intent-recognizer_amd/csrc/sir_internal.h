@@ -106,7 +106,8 @@ int sir_gemm_bf16x6_gen();
 size_t sir_gru_quad_xbuf_bytes(int batch);
 int sir_launch_gru_quad(hipStream_t st, bool save, const float* gi, const float* whh0, const float* whh1, const float* bhh0,
                         const float* bhh1, float* y, int B, int S, float* gates, float* xbuf, unsigned int* status,
-                        unsigned short* yplanes = nullptr);
+                        unsigned short* yplanes = nullptr, const void* wfrag0 = nullptr, const void* wfrag1 = nullptr);
+void sir_prep_whh_quad(hipStream_t st, const float* whh, void* frag);     // -> 768 * 256 * 6 bytes
 int sir_gru_variant();
 // paired-workgroup GRU backward recurrence (gru_pair.hip); SIR_GRU_BWD_VARIANT=0 selects the streaming kernel
 int sir_launch_gru_bwd_pair(hipStream_t st, const float* dy, const float* gates, const float* y, const float* whh0, const float* whh1,
