@@ -5,6 +5,7 @@
 #include "train_kernels.h"
 #include "bf16x6_kernels.h"
 #include "wgrad_bf16x6_kernel.h"
+#include "gemm_tn_bf16x6_kernel.h"
 
 namespace {
 
@@ -24,6 +25,17 @@ enum TrainBuf {
     TB_GFL,       // paired GRU status word
     TB_COUNT
 };
+
+// K splits of the four-job bf16x6 weight-gradient launch of one GRU layer (gemm_tn_bf16x6_kernel) and its slab floats
+static inline void tn_x6_plan(int tokens, int in_sz, int* tiles, int* kchunk, int* nsplit, size_t* slab_floats) {
+    const int t = 2 * ((768 / TN_BM) * ((in_sz + TN_BN - 1) / TN_BN) + (768 / TN_BM) * 1);
+    int ks = 256 / t;
+    ks = ks < 1 ? 1 : (ks > 16 ? 16 : ks);
+    const int kc = (((tokens + ks - 1) / ks) + TN_BK - 1) / TN_BK * TN_BK;
+    const int ns = (tokens + kc - 1) / kc;
+    *tiles = t; *kchunk = kc; *nsplit = ns;
+    *slab_floats = (size_t)ns * 2 * 768 * ((size_t)in_sz + 256);
+}
 
 struct TDims {
     int B, T, wp1, wp2, wp3, S;
@@ -94,6 +106,12 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     const size_t s_w2 = (size_t)d.wg2_blocks * wgrad_x6_ksplit(32, 64) * 9 * 64 * 32, s_g = (size_t)d.ksplits * 768 * 1024;
     if (s_w2 > slab) slab = s_w2;
     if (s_g > slab) slab = s_g;
+    for (int in_sz : {1024, 512}) {                       // slabs of the four-job bf16x6 weight-gradient launch (size independent of the batch)
+        int t_, kc_, ns_;
+        size_t need;
+        tn_x6_plan(d.B * d.S, in_sz, &t_, &kc_, &ns_, &need);
+        if (need > slab) slab = need;
+    }
     n[TB_SLAB] = slab + (size_t)WGR_PARTS * 9 * 128 * 64;       // + the partial sums of the two-pass wgrad reduce
     n[TB_XS] = (B * S * 1024 * 3 + 1) / 2;                       // ushort count / 2 (sizes are in floats)
     n[TB_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512 + 1) / 2;
@@ -351,6 +369,48 @@ static const int gru_bwd_variant = getenv("SIR_GRU_BWD_VARIANT") ? atoi(getenv("
         // bias gradients first: bsum_* alias the slab area used below
         hipLaunchKernelGGL(gru_bias_colsum_kernel, dim3(24, 2), dim3(256), 0, st, (const float*)bsum_i, (const float*)bsum_h, B,
                            g->gru_b_ih[2 * layer], g->gru_b_ih[2 * layer + 1], g->gru_b_hh[2 * layer], g->gru_b_hh[2 * layer + 1]);
+        static const int tn_x6 = getenv("SIR_GEMM_TN_X6") ? atoi(getenv("SIR_GEMM_TN_X6")) : 1;
+        if (tn_x6) {
+            // all four weight-gradient GEMMs of the layer (2 directions x {W_ih, W_hh}) in one bf16x6 launch
+            static bool tn_attr = false;
+            if (!tn_attr) {
+                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
+                tn_attr = true;
+            }
+            TnJobs jb{};
+            float* outs[4];
+            size_t sizes[4];
+            jb.njobs = 4;
+            int tiles = 0;
+            for (int dir = 0; dir < 2; ++dir) {
+                const int gi_idx = 2 * layer + dir;
+                const int ja = 2 * dir, jh = 2 * dir + 1;
+                jb.A[ja] = p.dgi + dir * 768; jb.lda[ja] = 1536; jb.B[ja] = xin; jb.ldb[ja] = in_sz; jb.N[ja] = in_sz; jb.shift[ja] = 0;
+                outs[ja] = g->gru_w_ih[gi_idx];
+                jb.A[jh] = p.dgh + dir * 768; jb.lda[jh] = 1536; jb.B[jh] = yout + dir * 256; jb.ldb[jh] = 512; jb.N[jh] = 256;
+                jb.shift[jh] = dir ? 1 : -1;
+                outs[jh] = g->gru_w_hh[gi_idx];
+            }
+            for (int j = 0; j < 4; ++j) {
+                jb.tile0[j] = tiles;
+                tiles += (768 / TN_BM) * ((jb.N[j] + TN_BN - 1) / TN_BN);
+                sizes[j] = (size_t)768 * jb.N[j];
+            }
+            jb.tile0[4] = tiles;
+            int tiles_chk, kchunk, nsplit;
+            size_t need;
+            tn_x6_plan(M, in_sz, &tiles_chk, &kchunk, &nsplit, &need);
+            size_t pos = 0;
+            for (int j = 0; j < 4; ++j) {
+                jb.slab[j] = p.slab + pos;
+                jb.slab_stride[j] = sizes[j];
+                pos += sizes[j] * nsplit;
+            }
+            hipLaunchKernelGGL(gemm_tn_bf16x6_kernel, dim3(tiles, nsplit), dim3(512), TN_LDS_BYTES, st, jb, 768, M, kchunk, S);
+            for (int j = 0; j < 4; ++j)
+                hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(sizes[j])), dim3(256), 0, st, (const float*)jb.slab[j], sizes[j], nsplit,
+                                   sizes[j], outs[j]);
+        } else
         for (int dir = 0; dir < 2; ++dir) {
             const int gi_idx = 2 * layer + dir;
             launch_tn(st, d, p.dgi + dir * 768, 1536, xin, in_sz, g->gru_w_ih[gi_idx], p.slab, 768, in_sz, M, 0, 0);
