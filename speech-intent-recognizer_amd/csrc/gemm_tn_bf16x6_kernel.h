@@ -20,12 +20,16 @@ constexpr size_t TN_LDS_BYTES = (size_t)3 * (TN_BM + TN_BN) * TN_ROWB;   // 92,1
 
 struct TnJobs {
     const float* A[4]; const float* B[4]; float* slab[4];   // slab[j] + z * slab_stride[j] receives split z of job j
+    const float* B2[4]; int brows[4];                        // rows k >= brows[j] of B come from B2[j] (two stacked matrices); 0 = off
     int lda[4], ldb[4], N[4], shift[4];
     size_t slab_stride[4];
     int tile0[5];                                            // first tile index of each job (prefix sums), tile0[njobs] = total
     int njobs;
 };
 
+// A_KM = true : A is [K][lda] (m contiguous: dW = dG^T X), staged transposed like B.
+// A_KM = false: A is [M][lda] (k contiguous: dX = dG [W; W_reverse]), staged with one 8-byte store per plane.
+template <bool A_KM>
 __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M, int K, int kchunk, int seq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tl[];
     unsigned char* AT = tl;                                  // [3][128][80]
@@ -38,6 +42,8 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
     const int m0 = (tile / ntn) * TN_BM, n0 = (tile % ntn) * TN_BN;
     const float* __restrict__ A = jobs.A[j];
     const float* __restrict__ B = jobs.B[j];
+    const float* __restrict__ B2 = jobs.B2[j];
+    const int brows = jobs.brows[j];
     const int k_begin = blockIdx.y * kchunk, k_end = min(K, k_begin + kchunk);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv >> 2, wn = wv & 3, i32 = lane & 31, kgrp = lane >> 5;
@@ -47,8 +53,14 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int it = tid + 512 * q, tok = k0 + (it & 31), m = m0 + 4 * (it >> 5);
-            pa[q] = (tok < k_end && m < M) ? *reinterpret_cast<const float4*>(A + (size_t)tok * lda + m) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int it = tid + 512 * q;
+            if (A_KM) {
+                const int tok = k0 + (it & 31), m = m0 + 4 * (it >> 5);
+                pa[q] = (tok < k_end && m < M) ? *reinterpret_cast<const float4*>(A + (size_t)tok * lda + m) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {                                         // item = (row it / 8, four consecutive k)
+                const int m = m0 + (it >> 3), k = k0 + 4 * (it & 7);
+                pa[q] = (k < k_end && m < M) ? *reinterpret_cast<const float4*>(A + (size_t)m * lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -60,7 +72,8 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
                 ok = ok && t >= 0 && t < seq;
                 src = tok + shift;
             }
-            pb[q] = ok ? *reinterpret_cast<const float4*>(B + (size_t)src * ldb + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* bsrc = (brows > 0 && src >= brows) ? B2 + (size_t)(src - brows) * ldb : B + (size_t)src * ldb;
+            pb[q] = ok ? *reinterpret_cast<const float4*>(bsrc + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto put = [&](const float4& v, unsigned char* base, size_t plane, int row4, int tok) {
@@ -81,7 +94,15 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int it = tid + 512 * q;
-            put(pa[q], AT, (size_t)TN_BM * TN_ROWB, 4 * (it >> 5), it & 31);
+            if (A_KM) put(pa[q], AT, (size_t)TN_BM * TN_ROWB, 4 * (it >> 5), it & 31);
+            else {
+                uint2 hh, mm, ll;
+                split3_quad(pa[q], hh, mm, ll);
+                unsigned char* d = AT + (size_t)(it >> 3) * TN_ROWB + (it & 7) * 8;
+                *reinterpret_cast<uint2*>(d) = hh;
+                *reinterpret_cast<uint2*>(d + (size_t)TN_BM * TN_ROWB) = mm;
+                *reinterpret_cast<uint2*>(d + 2 * (size_t)TN_BM * TN_ROWB) = ll;
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

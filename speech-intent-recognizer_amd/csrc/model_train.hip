@@ -374,7 +374,7 @@ static const int gru_bwd_variant = getenv("SIR_GRU_BWD_VARIANT") ? atoi(getenv("
             // all four weight-gradient GEMMs of the layer (2 directions x {W_ih, W_hh}) in one bf16x6 launch
             static bool tn_attr = false;
             if (!tn_attr) {
-                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
+                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
                 tn_attr = true;
             }
             TnJobs jb{};
@@ -406,7 +406,7 @@ static const int gru_bwd_variant = getenv("SIR_GRU_BWD_VARIANT") ? atoi(getenv("
                 jb.slab_stride[j] = sizes[j];
                 pos += sizes[j] * nsplit;
             }
-            hipLaunchKernelGGL(gemm_tn_bf16x6_kernel, dim3(tiles, nsplit), dim3(512), TN_LDS_BYTES, st, jb, 768, M, kchunk, S);
+            hipLaunchKernelGGL(gemm_tn_bf16x6_kernel<true>, dim3(tiles, nsplit), dim3(512), TN_LDS_BYTES, st, jb, 768, M, kchunk, S);
             for (int j = 0; j < 4; ++j)
                 hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(sizes[j])), dim3(256), 0, st, (const float*)jb.slab[j], sizes[j], nsplit,
                                    sizes[j], outs[j]);
@@ -419,6 +419,24 @@ static const int gru_bwd_variant = getenv("SIR_GRU_BWD_VARIANT") ? atoi(getenv("
         }
         // gradient wrt the layer input: dgi [M][1536] x [W_ih; W_ih_reverse] [1536][in]
         float* dxin = layer ? p.dy0 : p.dx0;
+static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6")) : 1;
+        if (nn_x6) {
+            static bool nn_attr = false;
+            if (!nn_attr) {
+                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
+                nn_attr = true;
+            }
+            TnJobs jn{};
+            jn.njobs = 1;
+            jn.A[0] = p.dgi; jn.lda[0] = 1536;
+            jn.B[0] = w->gru_w_ih[2 * layer]; jn.B2[0] = w->gru_w_ih[2 * layer + 1]; jn.brows[0] = 768; jn.ldb[0] = in_sz;
+            jn.N[0] = in_sz; jn.shift[0] = 0;
+            jn.slab[0] = dxin; jn.slab_stride[0] = 0;
+            jn.tile0[0] = 0;
+            const int ntiles = ((M + TN_BM - 1) / TN_BM) * ((in_sz + TN_BN - 1) / TN_BN);
+            jn.tile0[1] = ntiles;
+            hipLaunchKernelGGL(gemm_tn_bf16x6_kernel<false>, dim3(ntiles, 1), dim3(512), TN_LDS_BYTES, st, jn, M, 1536, 1536, 1);
+        } else
         hipLaunchKernelGGL((gemm_general_kernel<false, true>), dim3((in_sz + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M, 1), dim3(256), 0, st,
                            (const float*)p.dgi, 1536, w->gru_w_ih[2 * layer], w->gru_w_ih[2 * layer + 1], 768, in_sz, dxin, in_sz,
                            (size_t)0, M, in_sz, 1536, 1536, 0, 0);
