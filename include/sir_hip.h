@@ -199,6 +199,17 @@ int sir_ce_loss(sir_handle* h, const float* logits, const int64_t* labels, int b
 int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, const float* feats, const float* dlogits,
                         int batch, int t_frames, float dropout_p, uint64_t dropout_seed,
                         const sir_model_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
+/* The same backward in two halves, for data-parallel training that starts the gradient exchange early (SURVEY.md
+ * section 8(e)): SIR_BWD_HEAD_GRU writes the fc / attention / GRU gradients (96 % of the bytes; they are final after this
+ * call) and leaves d(loss)/d(GRU input) in the workspace; SIR_BWD_CNN, called next on the same workspace, writes the
+ * conv / BatchNorm gradients.  SIR_BWD_ALL = sir_model_train_bwd. */
+#define SIR_BWD_ALL 0
+#define SIR_BWD_HEAD_GRU 1
+#define SIR_BWD_CNN 2
+int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* w, const float* feats, const float* dlogits,
+                             int batch, int t_frames, float dropout_p, uint64_t dropout_seed,
+                             const sir_model_grads* grads, void* workspace, size_t workspace_bytes, int part,
+                             void* stream);
 int sir_model_train_workspace_offsets(const sir_handle* h, int batch, int t_frames, size_t* offsets, int n);
 
 /* optimizer.step() for torch.optim.Adam(lr, betas, eps, weight_decay) with coupled L2

@@ -15,6 +15,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 SIR_OK = 0
 WAVE_F32, WAVE_I16 = 0, 1
+BWD_ALL, BWD_HEAD_GRU, BWD_CNN = 0, 1, 2
 
 
 class FeatureConfig(C.Structure):
@@ -70,6 +71,9 @@ SIGNATURES = {
                               C.c_void_p]),
     "sir_model_train_bwd": (C.c_int, [C.c_void_p, C.POINTER(ModelWeights), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                       C.c_float, C.c_uint64, C.POINTER(ModelGrads), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sir_model_train_bwd_part": (C.c_int, [C.c_void_p, C.POINTER(ModelWeights), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                           C.c_float, C.c_uint64, C.POINTER(ModelGrads), C.c_void_p, C.c_size_t, C.c_int,
+                                           C.c_void_p]),
     "sir_model_train_workspace_offsets": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.c_int]),
     "sir_adam_step": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                 C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_float, C.c_float, C.c_float,

@@ -323,6 +323,18 @@ void launch_tn(hipStream_t st, const TDims& d, const float* A, int lda, const fl
 extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, const float* feats, const float* dlogits,
                                    int batch, int t_frames, float dropout_p, uint64_t dropout_seed,
                                    const sir_model_grads* g, void* workspace, size_t workspace_bytes, void* stream_) {
+    return sir_model_train_bwd_part(h, w, feats, dlogits, batch, t_frames, dropout_p, dropout_seed, g, workspace, workspace_bytes,
+                                    SIR_BWD_ALL, stream_);
+}
+
+extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* w, const float* feats, const float* dlogits,
+                                        int batch, int t_frames, float dropout_p, uint64_t dropout_seed,
+                                        const sir_model_grads* g, void* workspace, size_t workspace_bytes, int part,
+                                        void* stream_) {
+    if (part != SIR_BWD_ALL && part != SIR_BWD_HEAD_GRU && part != SIR_BWD_CNN) {
+        sir_set_error("sir_model_train_bwd_part: unknown part %d", part);
+        return SIR_EINVAL;
+    }
     TDims d;
     size_t off[TB_COUNT];
     int rc = check_common("sir_model_train_bwd", h, w, batch, t_frames, workspace, workspace_bytes, &d, off);
@@ -341,6 +353,7 @@ extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, co
     const float* y0in = dropout_p > 0.0f ? p.y0d : p.y0;
     const dim3 rgrid((B + GRU_BW - 1) / GRU_BW, 2);
 
+    if (part != SIR_BWD_CNN) {
     // ---- head: fc + attention pooling ----------------------------------------------------
     hipLaunchKernelGGL(fc_wgrad_kernel, dim3(C, 2), dim3(256), 0, st, dlogits, (const float*)p.ctx, g->fc_w, g->fc_b, B, C);
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, st, dlogits, w->fc_w, (const float*)p.y1, w->attn_w, w->attn_b,
@@ -445,6 +458,8 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
                                dropout_p, (unsigned long long)dropout_seed);
         KCHECK();
     }
+    }
+    if (part == SIR_BWD_HEAD_GRU) return SIR_OK;
 
     // ---- conv3 block -------------------------------------------------------------------------
     {
