@@ -206,3 +206,25 @@ def test_ragged_training_step_vs_oracle(sd, bsz, t):
             continue
         e = _rel(p.grad, ref_grads[name])[0]
         assert e < (tol if name.startswith(("conv", "bn")) else 2e-3), (name, e)
+
+
+def test_backward_in_two_halves_is_bit_identical(sd, monkeypatch):
+    """sir_model_train_bwd_part(HEAD_GRU) + (CNN) == sir_model_train_bwd (the split only exists to start the gradient
+    exchange early); checked by forcing the data-parallel code path with a one-rank gloo group."""
+    import torch.distributed as dist
+    inp = cases.model_inputs()
+    x, y = inp["x_train8"], inp["y_train8"]
+    m, _, _ = _hip_step(sd, x, y)
+    ref = {n: p.grad.clone() for n, p in m.named_parameters()}
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29655")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        monkeypatch.setattr(train_ops, "world_size", lambda: 2)          # take the two-bucket branch
+        monkeypatch.setattr(train_ops, "OVERLAP_GRAD_EXCHANGE", True)
+        m2, _, _ = _hip_step(sd, x, y)
+        for n, p in m2.named_parameters():
+            # sum over a 1-rank group = identity, then * 1/2 from the patched world size
+            assert torch.equal(p.grad * 2.0, ref[n]), n
+    finally:
+        dist.destroy_process_group()
