@@ -270,6 +270,12 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     }
 }
 
+// Measured with timing knock-outs (dbg): of the ~5 us step, MFMA phase 1.3 us, gates + stores 0.5 us, exchange ~2.1 us.  A
+// poll round issued with NO granule stores ahead of it in the same wave costs 0.6 us; behind the wave's own write-through
+// stores it costs 2.1 us -- but the remote stores need about that long to become visible anyway.  Tried and removed: a
+// dedicated publisher wave (re-reads the workgroup's values from LDS and stores all 1024 granules) with the other three
+// waves polling store-free: 173 us per layer against 125 us (the extra barrier and the single wave's 16 stores lengthen
+// the critical path more than the store-free polls shorten it).
 // Tried and removed: two utterance groups per cluster ("ping-pong": while group g's granules travel, group g^1
 // runs its MFMA/gate phase on the same resident weights; 64 workgroups instead of 128 at batch 256).  Correct,
 // but a phase took 4.1 us instead of the expected ~2.2 us (205 us per layer against 126 us), and with 2-3 HIP
