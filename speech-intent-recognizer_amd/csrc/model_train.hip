@@ -54,7 +54,7 @@ bool make_tdims(int batch, int t, TDims* d) {
     d->c2gx = (d->wp1 + 7) / 8;
     d->c3gx = (d->wp2 + 15) / 16;
     d->c3fx = (d->wp2 + 7) / 8;
-    d->wg2_rb = 16; d->wg3_rb = 8;                     // rows per workgroup of the weight-gradient kernels
+    d->wg2_rb = 32; d->wg3_rb = 16;                    // rows per workgroup of the weight-gradient kernels: one image each (256 workgroups at batch 256)
     d->wg2_blocks = batch * (32 / d->wg2_rb);
     d->wg3_blocks = batch * (16 / d->wg3_rb);
     const int K = batch * d->S;
