@@ -276,6 +276,11 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
 // dedicated publisher wave (re-reads the workgroup's values from LDS and stores all 1024 granules) with the other three
 // waves polling store-free: 173 us per layer against 125 us (the extra barrier and the single wave's 16 stores lengthen
 // the critical path more than the store-free polls shorten it).
+// Tried and removed: THREE utterance groups per cluster visited round robin (a group's granules then have two whole phases,
+// > 4 us, to arrive; 48 workgroups at batch 256): results identical, but a phase costs 2.5 us of MFMA + gates + barrier plus
+// ~0.9 us for the poll round even though its data has long arrived, i.e. 250 us per layer; with 2-3 streams the pipeline
+// ran at 344-370 k utterances/s against 390 k.  A timing knock-out of the whole exchange in THIS kernel (72 us per layer)
+// bounds what hiding the exchange could give: 431 k with two streams (+11 %).
 // Tried and removed: two utterance groups per cluster ("ping-pong": while group g's granules travel, group g^1
 // runs its MFMA/gate phase on the same resident weights; 64 workgroups instead of 128 at batch 256).  Correct,
 // but a phase took 4.1 us instead of the expected ~2.2 us (205 us per layer against 126 us), and with 2-3 HIP
