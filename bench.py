@@ -415,7 +415,9 @@ def main():
                                    "resident in HBM -> 64-mel log-mel [64,200] -> CNNAudioGRU(31) forward -> argmax",
                        "batch_per_gpu": BATCH, "clip_samples": CLIP_LEN, "n_mels": 64, "frames": T_PAD,
                        "num_classes": NUM_CLASSES, "parallelism": f"utterance-sharded x{world}, no data-path collective",
-                       "streams_per_gpu": ns},
+                       "streams_per_gpu": ns,
+                       "arithmetic": "fp32 accuracy end to end: contractions as bf16x6 (three-way bf16 split of both operands, six "
+                                     "v_mfma_f32_32x32x16_bf16 products, f32 accumulation), everything else fp32 VALU"},
             "roofline": roofline,
             "kernels_avg_ms": {k: round(v, 5) for k, v in kernel_ms.items()},
             "features_stage": {"bound": "hbm", "avg_ms": round(feat_ms, 5),
