@@ -20,6 +20,11 @@ from .featurizer import get_featurizer
 
 _seed_counter = itertools.count(1)
 OVERLAP_GRAD_EXCHANGE = os.environ.get("SIR_DDP_OVERLAP", "1") != "0"
+HAND_OVER_GRADS = os.environ.get("SIR_HAND_OVER_GRADS", "1") != "0"
+
+
+def _has_grad_hooks(p):
+    return bool(getattr(p, "_backward_hooks", None)) or bool(getattr(p, "_post_accumulate_grad_hooks", None))
 
 
 def param_list(mod):
@@ -97,8 +102,7 @@ class _TrainStep(torch.autograd.Function):
                                      logits.data_ptr(), ws.data_ptr(), ws.numel(), _native.current_stream_ptr())
         _native.check(rc, "sir_model_train_fwd")
         ops.bump_weights_epoch()                     # BN running statistics were updated in place
-        for i in (1, 2, 3):
-            getattr(mod, f"bn{i}").num_batches_tracked.add_(1)
+        torch._foreach_add_([getattr(mod, f"bn{i}").num_batches_tracked for i in (1, 2, 3)], 1)
         ctx.mod, ctx.x, ctx.seed, ctx.dropout_p, ctx.ws = mod, x, seed, float(dropout_p), ws
         return logits
 
@@ -112,6 +116,12 @@ class _TrainStep(torch.autograd.Function):
         dlogits = dlogits.contiguous()
         bsz, _, t = x.shape
         grads = st["grads"]
+        params = param_list(mod)
+        # a .grad left over from the previous step that still aliases the flat buffer (no zero_grad in between:
+        # gradient accumulation) must be detached from it before the kernels overwrite the buffer
+        for p, v in zip(params, grads.views):
+            if p.grad is not None and p.grad.data_ptr() == v.data_ptr():
+                p.grad = p.grad.clone()
 
         def run(part):
             rc = lib.sir_model_train_bwd_part(h, C.byref(w), x.data_ptr(), dlogits.data_ptr(), bsz, t, ctx.dropout_p, ctx.seed,
@@ -134,7 +144,15 @@ class _TrainStep(torch.autograd.Function):
         else:
             run(_native.BWD_ALL)
             all_reduce_mean_(grads.flat)            # the one exchange step of data-parallel training
-        return (None, None, None) + tuple(grads.views)
+        need = ctx.needs_input_grad[3:]
+        if HAND_OVER_GRADS and all(p.grad is None and not _has_grad_hooks(p) for p in params):
+            # zero_grad(set_to_none=True) (train.py:90): the views of the flat buffer BECOME the .grad tensors; returning
+            # them through autograd would make AccumulateGrad clone all 29 of them (29 copy launches per step)
+            for p, v, n in zip(params, grads.views, need):
+                if n:
+                    p.grad = v
+            return (None, None, None) + (None,) * len(params)
+        return (None, None, None) + tuple(v if n else None for v, n in zip(grads.views, need))
 
 
 def forward_train(mod, x):

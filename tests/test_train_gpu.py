@@ -228,3 +228,32 @@ def test_backward_in_two_halves_is_bit_identical(sd, monkeypatch):
             assert torch.equal(p.grad * 2.0, ref[n]), n
     finally:
         dist.destroy_process_group()
+
+
+def test_gradient_hand_over_matches_autograd_accumulation(sd, monkeypatch):
+    """After zero_grad(set_to_none=True) the flat-buffer views become .grad directly (no AccumulateGrad clones); the values
+    must equal the autograd path's, a second backward without zero_grad must ACCUMULATE (not alias the buffer the
+    kernels overwrite), and a frozen parameter must stay without gradient."""
+    inp = cases.model_inputs()
+    x, y = inp["x_train8"], inp["y_train8"]
+    monkeypatch.setattr(train_ops, "HAND_OVER_GRADS", False)
+    m0, _, _ = _hip_step(sd, x, y)
+    ref = {n: p.grad.clone() for n, p in m0.named_parameters()}
+    monkeypatch.setattr(train_ops, "HAND_OVER_GRADS", True)
+    m1, _, _ = _hip_step(sd, x, y)
+    flat = m1._sir_train["grads"].flat
+    for n, p in m1.named_parameters():
+        assert torch.equal(p.grad, ref[n]), n
+        assert flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel(), n     # handed over, not cloned
+    # accumulate: same batch again without zero_grad (dropout off in _hip_step's module => identical gradients)
+    loss = train_ops.fused_cross_entropy(m1(x.to(DEV)), y.to(DEV))
+    loss.backward()
+    for n, p in m1.named_parameters():
+        assert torch.allclose(p.grad, 2.0 * ref[n], rtol=1e-6, atol=1e-9), n
+    # frozen parameter
+    for p in m1.parameters():
+        p.grad = None
+    m1.fc.bias.requires_grad_(False)
+    train_ops.fused_cross_entropy(m1(x.to(DEV)), y.to(DEV)).backward()
+    assert m1.fc.bias.grad is None
+    assert torch.equal(m1.fc.weight.grad, ref["fc.weight"])
