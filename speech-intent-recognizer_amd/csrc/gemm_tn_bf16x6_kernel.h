@@ -17,6 +17,7 @@
 constexpr int TN_BM = 128, TN_BN = 256, TN_BK = 32;
 constexpr int TN_ROWB = TN_BK * 2 + 16;                      // 80 B per LDS row: 5 sixteen-byte slots (odd -> conflict-free b128 reads)
 constexpr size_t TN_LDS_BYTES = (size_t)3 * (TN_BM + TN_BN) * TN_ROWB;   // 92,160 B
+constexpr size_t TN_LDS_BYTES_64 = (size_t)3 * (64 + TN_BN) * TN_ROWB;    // 76,800 B (BM = 64)
 
 struct TnJobs {
     const float* A[4]; const float* B[4]; float* slab[4];   // slab[j] + z * slab_stride[j] receives split z of job j
@@ -29,30 +30,35 @@ struct TnJobs {
 
 // A_KM = true : A is [K][lda] (m contiguous: dW = dG^T X), staged transposed like B.
 // A_KM = false: A is [M][lda] (k contiguous: dX = dG [W; W_reverse]), staged with one 8-byte store per plane.
-template <bool A_KM>
+// BM = 128: waves 2 x 4, wave tile 64 x 64.  BM = 64: waves 1 x 8, wave tile 64 x 32 -- twice the workgroups for outputs
+// that would otherwise leave most CUs idle (layer-1 dX: 6400 x 512 is only 100 tiles of 128 x 256).
+template <bool A_KM, int BM = TN_BM>
 __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M, int K, int kchunk, int seq) {
+    static_assert(BM == 128 || BM == 64, "tile rows");
+    constexpr int NC = BM == 128 ? 2 : 1;                    // 32-column accumulators per wave
+    constexpr int NAQ = BM * 8 / 512;                        // A staging items per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char tl[];
-    unsigned char* AT = tl;                                  // [3][128][80]
-    unsigned char* BT = tl + (size_t)3 * TN_BM * TN_ROWB;    // [3][256][80]
+    unsigned char* AT = tl;                                  // [3][BM][80]
+    unsigned char* BT = tl + (size_t)3 * BM * TN_ROWB;       // [3][256][80]
     int j = 0;
     while (j + 1 < jobs.njobs && (int)blockIdx.x >= jobs.tile0[j + 1]) ++j;
     const int tile = blockIdx.x - jobs.tile0[j];
     const int N = jobs.N[j], lda = jobs.lda[j], ldb = jobs.ldb[j], shift = jobs.shift[j];
     const int ntn = (N + TN_BN - 1) / TN_BN;
-    const int m0 = (tile / ntn) * TN_BM, n0 = (tile % ntn) * TN_BN;
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * TN_BN;
     const float* __restrict__ A = jobs.A[j];
     const float* __restrict__ B = jobs.B[j];
     const float* __restrict__ B2 = jobs.B2[j];
     const int brows = jobs.brows[j];
     const int k_begin = blockIdx.y * kchunk, k_end = min(K, k_begin + kchunk);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv >> 2, wn = wv & 3, i32 = lane & 31, kgrp = lane >> 5;
+    const int wm = BM == 128 ? wv >> 2 : 0, wn = BM == 128 ? wv & 3 : wv, i32 = lane & 31, kgrp = lane >> 5;
 
     // staging items: token = it % 32, 4-column group = it / 32.  A: 128 / 4 * 32 = 1024 items (2 per thread), B: 2048 (4)
-    float4 pa[2], pb[4];
+    float4 pa[NAQ], pb[4];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NAQ; ++q) {
             const int it = tid + 512 * q;
             if (A_KM) {
                 const int tok = k0 + (it & 31), m = m0 + 4 * (it >> 5);
@@ -92,16 +98,16 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
     };
     auto stage = [&]() {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NAQ; ++q) {
             const int it = tid + 512 * q;
-            if (A_KM) put(pa[q], AT, (size_t)TN_BM * TN_ROWB, 4 * (it >> 5), it & 31);
+            if (A_KM) put(pa[q], AT, (size_t)BM * TN_ROWB, 4 * (it >> 5), it & 31);
             else {
                 uint2 hh, mm, ll;
                 split3_quad(pa[q], hh, mm, ll);
                 unsigned char* d = AT + (size_t)(it >> 3) * TN_ROWB + (it & 7) * 8;
                 *reinterpret_cast<uint2*>(d) = hh;
-                *reinterpret_cast<uint2*>(d + (size_t)TN_BM * TN_ROWB) = mm;
-                *reinterpret_cast<uint2*>(d + 2 * (size_t)TN_BM * TN_ROWB) = ll;
+                *reinterpret_cast<uint2*>(d + (size_t)BM * TN_ROWB) = mm;
+                *reinterpret_cast<uint2*>(d + 2 * (size_t)BM * TN_ROWB) = ll;
             }
         }
 #pragma unroll
@@ -111,16 +117,16 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NC];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
 
     const unsigned char* arow = AT + (size_t)(wm * 64 + i32) * TN_ROWB + kgrp * 16;
-    const unsigned char* brow = BT + (size_t)(wn * 64 + i32) * TN_ROWB + kgrp * 16;
+    const unsigned char* brow = BT + (size_t)(wn * 32 * NC + i32) * TN_ROWB + kgrp * 16;
     fetch(k_begin);
     for (int k0 = k_begin; k0 < k_end; k0 += TN_BK) {
         __syncthreads();                                     // previous stage consumed
@@ -129,14 +135,14 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 af[2][3], bf[2][3];
+            bf16x8 af[2][3], bf[NC][3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
-                    af[a][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(arow + (size_t)p * TN_BM * TN_ROWB + (size_t)a * 32 * TN_ROWB + s * 32));
+                    af[a][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(arow + (size_t)p * BM * TN_ROWB + (size_t)a * 32 * TN_ROWB + s * 32));
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < NC; ++c)
                     bf[c][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(brow + (size_t)p * TN_BN * TN_ROWB + (size_t)c * 32 * TN_ROWB + s * 32));
             }
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int c = 0; c < 2; ++c)
+                    for (int c = 0; c < NC; ++c)
                         acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA[t6]], bf[c][PB[t6]], acc[a][c], 0, 0, 0);
         }
     }
@@ -153,8 +159,8 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int n = n0 + wn * 64 + c * 32 + i32;
+        for (int c = 0; c < NC; ++c) {
+            const int n = n0 + wn * 32 * NC + c * 32 + i32;
             if (n >= N) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

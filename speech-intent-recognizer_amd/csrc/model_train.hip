@@ -437,6 +437,7 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
             static bool nn_attr = false;
             if (!nn_attr) {
                 SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
+                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES_64));
                 nn_attr = true;
             }
             TnJobs jn{};
@@ -446,9 +447,16 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
             jn.N[0] = in_sz; jn.shift[0] = 0;
             jn.slab[0] = dxin; jn.slab_stride[0] = 0;
             jn.tile0[0] = 0;
-            const int ntiles = ((M + TN_BM - 1) / TN_BM) * ((in_sz + TN_BN - 1) / TN_BN);
-            jn.tile0[1] = ntiles;
-            hipLaunchKernelGGL(gemm_tn_bf16x6_kernel<false>, dim3(ntiles, 1), dim3(512), TN_LDS_BYTES, st, jn, M, 1536, 1536, 1);
+            const int ntn = (in_sz + TN_BN - 1) / TN_BN;
+            int ntiles = ((M + TN_BM - 1) / TN_BM) * ntn;
+            if (ntiles < 160) {                              // too few 128-row tiles to fill the CUs: 64-row tiles
+                ntiles = ((M + 63) / 64) * ntn;
+                jn.tile0[1] = ntiles;
+                hipLaunchKernelGGL((gemm_tn_bf16x6_kernel<false, 64>), dim3(ntiles, 1), dim3(512), TN_LDS_BYTES_64, st, jn, M, 1536, 1536, 1);
+            } else {
+                jn.tile0[1] = ntiles;
+                hipLaunchKernelGGL(gemm_tn_bf16x6_kernel<false>, dim3(ntiles, 1), dim3(512), TN_LDS_BYTES, st, jn, M, 1536, 1536, 1);
+            }
         } else
         hipLaunchKernelGGL((gemm_general_kernel<false, true>), dim3((in_sz + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M, 1), dim3(256), 0, st,
                            (const float*)p.dgi, 1536, w->gru_w_ih[2 * layer], w->gru_w_ih[2 * layer + 1], 768, in_sz, dxin, in_sz,
@@ -470,7 +478,7 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
                            scale + 96, shift + 96, smean + 96, sinv + 96, p.stats, B, 16, d.wp2, 128, 8, d.wp3, ppb);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, nblk, 128,
                            (double)B * 16 * d.wp2, g->bn_w[2], g->bn_b[2], mdy + 96, mdyx + 96);
-        hipLaunchKernelGGL(bn_bwd_dz_kernel<true>, dim3(grid_for((size_t)B * 16 * d.wp2 * 32)), dim3(256), 0, st, (const float*)p.z3,
+        hipLaunchKernelGGL(bn_bwd_dz_kernel<true>, dim3(grid_for((size_t)B * 8 * ((d.wp2 + 1) / 2) * 32)), dim3(256), 0, st, (const float*)p.z3,
                            (const float*)p.dx0, scale + 96, shift + 96, smean + 96, sinv + 96, mdy + 96, mdyx + 96, p.dz3, B, 16,
                            d.wp2, 128, 8, d.wp3);
         const int Wk = (d.wp2 + 1) & ~1;
@@ -525,7 +533,7 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
                            scale + 32, shift + 32, smean + 32, sinv + 32, p.stats, B, 32, d.wp1, 64, 16, d.wp2, ppb);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, nblk, 64,
                            (double)B * 32 * d.wp1, g->bn_w[1], g->bn_b[1], mdy + 32, mdyx + 32);
-        hipLaunchKernelGGL(bn_bwd_dz_kernel<false>, dim3(grid_for((size_t)B * 32 * d.wp1 * 16)), dim3(256), 0, st, (const float*)p.z2,
+        hipLaunchKernelGGL(bn_bwd_dz_kernel<false>, dim3(grid_for((size_t)B * 16 * ((d.wp1 + 1) / 2) * 16)), dim3(256), 0, st, (const float*)p.z2,
                            (const float*)p.da2, scale + 32, shift + 32, smean + 32, sinv + 32, mdy + 32, mdyx + 32, p.dz2, B, 32,
                            d.wp1, 64, 16, d.wp2);
         const int Wk = (d.wp1 + 1) & ~1;

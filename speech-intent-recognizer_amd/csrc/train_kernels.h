@@ -682,46 +682,62 @@ static __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float
     }
 }
 
+// first maximum of the 2x2 window (PyTorch's max-pool tie rule: row-major scan, strict >), -1 if ReLU blocks it
+__device__ __forceinline__ int route_arg(float y00, float y01, float y10, float y11) {
+    float best = y00; int arg = 0;
+    if (y01 > best) { best = y01; arg = 1; }
+    if (y10 > best) { best = y10; arg = 2; }
+    if (y11 > best) { best = y11; arg = 3; }
+    return best > 0.0f ? arg : -1;
+}
+
+// thread = one 2x2 window x 4 channels: the four z values are read once (a thread per PIXEL re-read its three window
+// neighbours for the routing: 5 loads per output against 1.25 here), the pooled gradient once per window
 template <bool GRU_IN>
 __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const float* __restrict__ z, const float* __restrict__ da,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ mdy, const float* __restrict__ mdyx,
                                                          float* __restrict__ dz, int B, int H, int W, int C, int Hp, int Wp) {
-    const int c4n = C / 4;
-    const size_t total = (size_t)B * H * W * c4n;
+    const int c4n = C / 4, Hc = (H + 1) / 2, Wc = (W + 1) / 2;           // cells cover an odd last row / column too
+    const size_t total = (size_t)B * Hc * Wc * c4n;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int cc = idx % c4n;
         size_t rest = idx / c4n;
-        const int x = rest % W; rest /= W;
-        const int yy_ = rest % H;
-        const int b = rest / H;
+        const int cx = rest % Wc; rest /= Wc;
+        const int cy = rest % Hc;
+        const int b = rest / Hc;
         const float4 s = *reinterpret_cast<const float4*>(scale + cc * 4), t = *reinterpret_cast<const float4*>(shift + cc * 4);
         const float4 mu = *reinterpret_cast<const float4*>(mean + cc * 4), is = *reinterpret_cast<const float4*>(invstd + cc * 4);
         const float4 m1 = *reinterpret_cast<const float4*>(mdy + cc * 4), m2 = *reinterpret_cast<const float4*>(mdyx + cc * 4);
-        const float4 zc = *reinterpret_cast<const float4*>(z + (((size_t)b * H + yy_) * W + x) * C + cc * 4);
-        float4 dyv = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int py = yy_ >> 1, px = x >> 1;
-        if (py < Hp && px < Wp) {
-            const float4 g = load_da4<GRU_IN>(da, b, py, px, cc, Hp, Wp, C);
-            float4 yv[4];
+        float4 zq[4];
+        bool ok[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 zq = *reinterpret_cast<const float4*>(z + (((size_t)b * H + 2 * py + (q >> 1)) * W + 2 * px + (q & 1)) * C + cc * 4);
-                yv[q] = make_float4(fmaf(zq.x, s.x, t.x), fmaf(zq.y, s.y, t.y), fmaf(zq.z, s.z, t.z), fmaf(zq.w, s.w, t.w));
-            }
-            const int pos = ((yy_ & 1) << 1) | (x & 1);
-            dyv.x = route1(yv[0].x, yv[1].x, yv[2].x, yv[3].x, pos, g.x);
-            dyv.y = route1(yv[0].y, yv[1].y, yv[2].y, yv[3].y, pos, g.y);
-            dyv.z = route1(yv[0].z, yv[1].z, yv[2].z, yv[3].z, pos, g.z);
-            dyv.w = route1(yv[0].w, yv[1].w, yv[2].w, yv[3].w, pos, g.w);
+        for (int q = 0; q < 4; ++q) {
+            const int y = 2 * cy + (q >> 1), x = 2 * cx + (q & 1);
+            ok[q] = y < H && x < W;
+            zq[q] = ok[q] ? *reinterpret_cast<const float4*>(z + (((size_t)b * H + y) * W + x) * C + cc * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        float4 o;
-        o.x = s.x * (dyv.x - m1.x - (zc.x - mu.x) * is.x * m2.x);
-        o.y = s.y * (dyv.y - m1.y - (zc.y - mu.y) * is.y * m2.y);
-        o.z = s.z * (dyv.z - m1.z - (zc.z - mu.z) * is.z * m2.z);
-        o.w = s.w * (dyv.w - m1.w - (zc.w - mu.w) * is.w * m2.w);
-        *reinterpret_cast<float4*>(dz + (((size_t)b * H + yy_) * W + x) * C + cc * 4) = o;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        int ax = -1, ay = -1, az = -1, aw = -1;
+        if (cy < Hp && cx < Wp) {                                        // pooled window (all four pixels exist)
+            g = load_da4<GRU_IN>(da, b, cy, cx, cc, Hp, Wp, C);
+            ax = route_arg(fmaf(zq[0].x, s.x, t.x), fmaf(zq[1].x, s.x, t.x), fmaf(zq[2].x, s.x, t.x), fmaf(zq[3].x, s.x, t.x));
+            ay = route_arg(fmaf(zq[0].y, s.y, t.y), fmaf(zq[1].y, s.y, t.y), fmaf(zq[2].y, s.y, t.y), fmaf(zq[3].y, s.y, t.y));
+            az = route_arg(fmaf(zq[0].z, s.z, t.z), fmaf(zq[1].z, s.z, t.z), fmaf(zq[2].z, s.z, t.z), fmaf(zq[3].z, s.z, t.z));
+            aw = route_arg(fmaf(zq[0].w, s.w, t.w), fmaf(zq[1].w, s.w, t.w), fmaf(zq[2].w, s.w, t.w), fmaf(zq[3].w, s.w, t.w));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!ok[q]) continue;
+            const int y = 2 * cy + (q >> 1), x = 2 * cx + (q & 1);
+            float4 o;
+            o.x = s.x * ((ax == q ? g.x : 0.0f) - m1.x - (zq[q].x - mu.x) * is.x * m2.x);
+            o.y = s.y * ((ay == q ? g.y : 0.0f) - m1.y - (zq[q].y - mu.y) * is.y * m2.y);
+            o.z = s.z * ((az == q ? g.z : 0.0f) - m1.z - (zq[q].z - mu.z) * is.z * m2.z);
+            o.w = s.w * ((aw == q ? g.w : 0.0f) - m1.w - (zq[q].w - mu.w) * is.w * m2.w);
+            *reinterpret_cast<float4*>(dz + (((size_t)b * H + y) * W + x) * C + cc * 4) = o;
+        }
     }
 }
 
