@@ -41,11 +41,12 @@ __device__ __forceinline__ void split3_quad(const float4& v, uint2& h, uint2& m,
 }
 
 // in [rows][K] fp32 (row stride ld_in) -> planes [3][rows][K] bf16; one thread = 8 consecutive k
-static __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ in, int ld_in, unsigned short* __restrict__ out,
-                                                             size_t rows, int K) {
+// (gidx / nthreads: linear thread index and thread count of the launch -- or of the job's share of a multi-job launch)
+__device__ __forceinline__ void split3_rows(const float* __restrict__ in, int ld_in, unsigned short* __restrict__ out, size_t rows, int K,
+                                            size_t gidx, size_t nthreads) {
     const int k8n = K / 8;
     const size_t total = rows * k8n, plane = rows * (size_t)K;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    for (size_t idx = gidx; idx < total; idx += nthreads) {
         const size_t row = idx / k8n;
         const int k8 = idx % k8n;
         const float4 v0 = *reinterpret_cast<const float4*>(in + row * ld_in + k8 * 8);
@@ -58,6 +59,10 @@ static __global__ __launch_bounds__(256) void split3_kernel(const float* __restr
         *reinterpret_cast<uint4*>(out + plane + o) = make_uint4(m0.x, m0.y, m1.x, m1.y);
         *reinterpret_cast<uint4*>(out + 2 * plane + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
+}
+static __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ in, int ld_in, unsigned short* __restrict__ out,
+                                                             size_t rows, int K) {
+    split3_rows(in, ld_in, out, rows, K, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
 }
 
 // C[m][z*N + n] = sum_k A[m][k] * Bz[n][k] + biasz[n] with A, B given as bf16x3 planes.
@@ -360,8 +365,7 @@ constexpr int conv_bf16x6_row_bytes(int PC, bool pad = true) {
 }
 constexpr size_t conv_bf16x6_lds_bytes(int PR, int PC, bool pad = true) { return (size_t)3 * (8 * PR + 2) * conv_bf16x6_row_bytes(PC, pad); }
 
-static __global__ void prep_conv_w_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin, int cout) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void prep_conv_w_bf16x3_elem(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin, int cout, int idx) {
     const int total = cin * 9 * cout;
     if (idx >= total) return;
     const int e = idx & 15, co = (idx >> 4) % cout, g = (idx >> 4) / cout;
@@ -372,11 +376,13 @@ static __global__ void prep_conv_w_bf16x3_kernel(const float* __restrict__ w, un
     wpb[(size_t)total + idx] = m;
     wpb[2 * (size_t)total + idx] = l;
 }
+static __global__ void prep_conv_w_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin, int cout) {
+    prep_conv_w_bf16x3_elem(w, wpb, cin, cout, blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // data-gradient weights as bf16x3 planes: roles of the channel axes swapped, taps flipped (cf. prep_conv_wT_kernel);
 // output channels co' = forward INPUT channels, 16-groups over the forward OUTPUT channels
-static __global__ void prep_conv_wT_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin_f, int cout_f) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void prep_conv_wT_bf16x3_elem(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin_f, int cout_f, int idx) {
     const int total = cin_f * 9 * cout_f;
     if (idx >= total) return;
     const int e = idx & 15, cop = (idx >> 4) % cin_f, g = (idx >> 4) / cin_f;
@@ -386,6 +392,9 @@ static __global__ void prep_conv_wT_bf16x3_kernel(const float* __restrict__ w, u
     wpb[idx] = h;
     wpb[(size_t)total + idx] = m;
     wpb[2 * (size_t)total + idx] = l;
+}
+static __global__ void prep_conv_wT_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin_f, int cout_f) {
+    prep_conv_wT_bf16x3_elem(w, wpb, cin_f, cout_f, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 template <int CIN, int COUT, int PR, int PC, int OUT_MODE, int MT>

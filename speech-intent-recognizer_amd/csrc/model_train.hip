@@ -2,8 +2,8 @@
 // activations (sir_model_train_fwd), cross-entropy (sir_ce_loss), full backward
 // (sir_model_train_bwd) and multi-tensor Adam (sir_adam_step).  Replaces the body of
 // train_epoch (scripts/train.py:90-107: forward, criterion, loss.backward(), optimizer.step()).
-#include "train_kernels.h"
 #include "bf16x6_kernels.h"
+#include "train_kernels.h"
 #include "wgrad_bf16x6_kernel.h"
 #include "gemm_tn_bf16x6_kernel.h"
 
@@ -216,11 +216,26 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     const int B = d.B, S = d.S, T = d.T;
     float *scale = p.bn, *shift = p.bn + 224, *smean = p.bn + 448, *sinv = p.bn + 672;
 
-    hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], p.wcb2, 32, 64);
-    hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], p.wcb3, 64, 128);
-    for (int dir = 0; dir < 2; ++dir) {
-        hipLaunchKernelGGL(split3_kernel, dim3(384), dim3(256), 0, st, w->gru_w_ih[dir], 1024, p.wsl0 + (size_t)dir * 3 * 768 * 1024, (size_t)768, 1024);
-        hipLaunchKernelGGL(split3_kernel, dim3(192), dim3(256), 0, st, w->gru_w_ih[2 + dir], 512, p.wsl1 + (size_t)dir * 3 * 768 * 512, (size_t)768, 512);
+    {   // all weight re-layouts of this step, the backward's included (the weights do not change before it runs)
+        PrepJobs pj{};
+        int nj = 0, blocks = 0;
+        auto add = [&](int kind, const float* src, void* dst, int a, int b, int nblk) {
+            pj.kind[nj] = kind; pj.src[nj] = src; pj.dst[nj] = dst; pj.a[nj] = a; pj.b[nj] = b; pj.block0[nj] = blocks;
+            blocks += nblk; ++nj;
+        };
+        add(1, w->conv_w[1], p.wcb2, 32, 64, (32 * 9 * 64 + 255) / 256);
+        add(1, w->conv_w[2], p.wcb3, 64, 128, (64 * 9 * 128 + 255) / 256);
+        add(2, w->conv_w[1], p.wcb2t, 32, 64, (32 * 9 * 64 + 255) / 256);
+        add(2, w->conv_w[2], p.wcb3t, 64, 128, (64 * 9 * 128 + 255) / 256);
+        for (int dir = 0; dir < 2; ++dir) {
+            add(0, w->gru_w_ih[dir], p.wsl0 + (size_t)dir * 3 * 768 * 1024, 1024, 768, 384);
+            add(0, w->gru_w_ih[2 + dir], p.wsl1 + (size_t)dir * 3 * 768 * 512, 512, 768, 192);
+        }
+        for (int i = 0; i < 4; ++i) add(3, w->gru_w_hh[i], p.wr4 + (size_t)i * 768 * 256, 0, 0, 768);
+        pj.block0[nj] = blocks;
+        pj.njobs = nj;
+        static_assert(PREP_MAX_JOBS >= 12, "job table");
+        hipLaunchKernelGGL(train_prep_kernel, dim3(blocks), dim3(256), 0, st, pj);
     }
     KCHECK();
 
@@ -360,9 +375,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                        p.dy1, daw_part, dab_part, S, C);
     hipLaunchKernelGGL(colsum_kernel, dim3(8), dim3(256), 0, st, (const float*)daw_part, B, 512, 512, g->attn_w);
     hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, st, (const float*)dab_part, B, 1, 1, g->attn_b);
-    for (int i = 0; i < 4; ++i)
-        hipLaunchKernelGGL(prep_whh_bwd_kernel, dim3(768), dim3(256), 0, st, w->gru_w_hh[i], p.wr4 + (size_t)i * 768 * 256);
-    KCHECK();
+    KCHECK();                                          // (W_hh re-layout p.wr4: train_prep_kernel of the forward)
 
     // ---- GRU layers, top down ----------------------------------------------------------------
     for (int layer = 1; layer >= 0; --layer) {
@@ -420,9 +433,9 @@ static const int gru_bwd_variant = getenv("SIR_GRU_BWD_VARIANT") ? atoi(getenv("
                 pos += sizes[j] * nsplit;
             }
             hipLaunchKernelGGL(gemm_tn_bf16x6_kernel<true>, dim3(tiles, nsplit), dim3(512), TN_LDS_BYTES, st, jb, 768, M, kchunk, S);
-            for (int j = 0; j < 4; ++j)
-                hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(sizes[j])), dim3(256), 0, st, (const float*)jb.slab[j], sizes[j], nsplit,
-                                   sizes[j], outs[j]);
+            SlabJobs sj{};
+            for (int j = 0; j < 4; ++j) { sj.src[j] = jb.slab[j]; sj.out[j] = outs[j]; sj.n[j] = sizes[j]; }
+            hipLaunchKernelGGL(slab_reduce_jobs_kernel, dim3(grid_for(sizes[0]), 4), dim3(256), 0, st, sj, nsplit);
         } else
         for (int dir = 0; dir < 2; ++dir) {
             const int gi_idx = 2 * layer + dir;
@@ -512,7 +525,7 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 128 * 64 + 255) / 256), dim3(256), 0, st, (const float*)part, WGR_PARTS, 64, 128,
                                g->conv_w[2]);
         }
-        hipLaunchKernelGGL(prep_conv_wT_bf16x3_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], p.wcb3t, 64, 128);
+        // (data-gradient weights p.wcb3t: train_prep_kernel of the forward)
         constexpr size_t ldsd = conv_bf16x6_lds_bytes(2, 4);
         if (sir_conv_ns())
         hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<128, 64, 2, 4, 2, 0, 3, true>), dim3(d.c3gx, 1, B), dim3(256), ldsd, st, (const float*)p.dz3,
@@ -567,7 +580,7 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 32 + 255) / 256), dim3(256), 0, st, (const float*)part, WGR_PARTS, 32, 64,
                                g->conv_w[1]);
         }
-        hipLaunchKernelGGL(prep_conv_wT_bf16x3_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], p.wcb2t, 32, 64);
+        // (data-gradient weights p.wcb2t: train_prep_kernel of the forward)
         constexpr size_t ldsd = conv_bf16x6_lds_bytes(4, 2);
         if (sir_conv_ns())
         hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 32, 4, 2, 2, 0, 3, false>), dim3(d.c2gx, 1, B), dim3(256), conv_bf16x6_lds_bytes(4, 2, false), st, (const float*)p.dz2,

@@ -2,6 +2,7 @@
 // Included by model_train.hip.  Layouts as in model_kernels.h (NHWC activations).
 #pragma once
 #include "model_kernels.h"
+#include "bf16x6_kernels.h"
 
 // ------------------------------------------------------------------------------------------
 // BatchNorm with batch statistics
@@ -108,11 +109,20 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restri
     const int c4n = C / 4;
     const size_t total = (size_t)B * Hp * Wp * c4n;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int c4 = idx % c4n;
-        size_t rest = idx / c4n;
-        const int px = rest % Wp; rest /= Wp;
-        const int py = rest % Hp;
-        const int b = rest / Hp;
+        int c4, px, py, b;
+        if (!GRU_OUT) {
+            c4 = idx % c4n;
+            size_t rest = idx / c4n;
+            px = rest % Wp; rest /= Wp;
+            py = rest % Hp;
+            b = rest / Hp;
+        } else {                                      // py fastest: the lanes of a wave then fill whole 32-byte sectors of
+            py = idx % Hp;                            // the [c*Hp + py] feature rows (c4 fastest scattered single floats)
+            size_t rest = idx / Hp;
+            c4 = rest % c4n; rest /= c4n;
+            px = rest % Wp;
+            b = rest / Wp;
+        }
         const float4 s = *reinterpret_cast<const float4*>(scale + c4 * 4);
         const float4 t = *reinterpret_cast<const float4*>(shift + c4 * 4);
         float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -337,11 +347,52 @@ static __global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __res
 // Thread (u, b): gate math for hidden unit u of utterance b; thread (k, rs): partial of W_hh^T dgh
 // over gate rows [192 rs, 192 rs + 192).
 // ------------------------------------------------------------------------------------------
-static __global__ void prep_whh_bwd_kernel(const float* __restrict__ w, float* __restrict__ wr4) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // over 768*256, layout [row/4][k][4]
-    if (idx >= 768 * 256) return;
+__device__ __forceinline__ void prep_whh_bwd_elem(const float* __restrict__ w, float* __restrict__ wr4, int idx) {
+    if (idx >= 768 * 256) return;                                 // over 768*256, layout [row/4][k][4]
     const int e = idx & 3, k = (idx >> 2) & 255, r4 = idx >> 10;
     wr4[idx] = w[(size_t)(r4 * 4 + e) * 256 + k];
+}
+static __global__ void prep_whh_bwd_kernel(const float* __restrict__ w, float* __restrict__ wr4) {
+    prep_whh_bwd_elem(w, wr4, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Every per-step re-layout of the weights (they change with each optimizer step) in ONE launch: a dozen ~5 us launches
+// otherwise.  kind 0: split3_rows (a = ld_in = K, b = rows), 1: prep_conv_w_bf16x3 (a = cin, b = cout),
+// 2: prep_conv_wT_bf16x3 (a = cin_f, b = cout_f), 3: prep_whh_bwd.  Job j owns blocks [block0[j], block0[j+1]).
+constexpr int PREP_MAX_JOBS = 12;
+struct PrepJobs {
+    const float* src[PREP_MAX_JOBS];
+    void* dst[PREP_MAX_JOBS];
+    int kind[PREP_MAX_JOBS], a[PREP_MAX_JOBS], b[PREP_MAX_JOBS];
+    int block0[PREP_MAX_JOBS + 1];
+    int njobs;
+};
+static __global__ __launch_bounds__(256) void train_prep_kernel(PrepJobs jobs) {
+    int j = 0;
+    while (j + 1 < jobs.njobs && (int)blockIdx.x >= jobs.block0[j + 1]) ++j;
+    const int lb = blockIdx.x - jobs.block0[j], nb = jobs.block0[j + 1] - jobs.block0[j];
+    const int idx = lb * 256 + threadIdx.x;
+    const float* __restrict__ src = jobs.src[j];
+    switch (jobs.kind[j]) {
+        case 0: split3_rows(src, jobs.a[j], (unsigned short*)jobs.dst[j], (size_t)jobs.b[j], jobs.a[j], (size_t)idx, (size_t)nb * 256); break;
+        case 1: prep_conv_w_bf16x3_elem(src, (unsigned short*)jobs.dst[j], jobs.a[j], jobs.b[j], idx); break;
+        case 2: prep_conv_wT_bf16x3_elem(src, (unsigned short*)jobs.dst[j], jobs.a[j], jobs.b[j], idx); break;
+        default: prep_whh_bwd_elem(src, (float*)jobs.dst[j], idx); break;
+    }
+}
+
+// out_j[i] = sum_z slabs_j[z][i] for up to four jobs (blockIdx.y) with a common slab count; slab stride = n_j
+struct SlabJobs { const float* src[4]; float* out[4]; size_t n[4]; };
+static __global__ void slab_reduce_jobs_kernel(SlabJobs jobs, int nslab) {
+    const int j = blockIdx.y;
+    const size_t n = jobs.n[j];
+    const float* __restrict__ s = jobs.src[j];
+    float* __restrict__ o = jobs.out[j];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float a = 0.0f;
+        for (int z = 0; z < nslab; ++z) a += s[(size_t)z * n + i];
+        o[i] = a;
+    }
 }
 
 constexpr int GRU_BBW = 4;      // utterances per workgroup of the backward recurrence
