@@ -131,6 +131,8 @@ size_t tws_layout(const TDims& d, size_t* off) {
 }
 
 const int kBnC[3] = {32, 64, 128}, kBnO[3] = {0, 32, 96};
+// BatchNorm backward sums from the pooled activations (bn_bwd_reduce_pooled_kernel) instead of the raw conv outputs
+const int bn_reduce_pooled = getenv("SIR_BN_REDUCE_POOLED") ? atoi(getenv("SIR_BN_REDUCE_POOLED")) : 1;
 
 #define KCHECK() SIR_HIP_TRY(hipGetLastError())
 
@@ -487,9 +489,17 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
         const int ppb = 64;
         const size_t npix = (size_t)B * 8 * d.wp3;
         const int nblk = (int)((npix + ppb - 1) / ppb);
+        int nfin = nblk;
+        if (bn_reduce_pooled) {                       // from the pooled activations x0 (GRU layout) instead of z3
+            const int rows = B * d.wp3, rpb = 16;
+            nfin = (rows + rpb - 1) / rpb;
+            hipLaunchKernelGGL(bn_bwd_reduce_pooled_gru_kernel, dim3(nfin), dim3(256), 0, st, (const float*)p.x0, (const float*)p.dx0,
+                               (const float*)p.z3, w->bn_w[2], w->bn_b[2], scale + 96, shift + 96, smean + 96, sinv + 96, p.stats, rows,
+                               16, d.wp2, d.wp3, rpb);
+        } else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, st, (const float*)p.z3, (const float*)p.dx0,
                            scale + 96, shift + 96, smean + 96, sinv + 96, p.stats, B, 16, d.wp2, 128, 8, d.wp3, ppb);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, nblk, 128,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, nfin, 128,
                            (double)B * 16 * d.wp2, g->bn_w[2], g->bn_b[2], mdy + 96, mdyx + 96);
         hipLaunchKernelGGL(bn_bwd_dz_kernel<true>, dim3(grid_for((size_t)B * 8 * ((d.wp2 + 1) / 2) * 32)), dim3(256), 0, st, (const float*)p.z3,
                            (const float*)p.dx0, scale + 96, shift + 96, smean + 96, sinv + 96, mdy + 96, mdyx + 96, p.dz3, B, 16,
@@ -542,6 +552,11 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
         const int ppb = 64;
         const size_t npix = (size_t)B * 16 * d.wp2;
         const int nblk = (int)((npix + ppb - 1) / ppb);
+        if (bn_reduce_pooled)
+        hipLaunchKernelGGL(bn_bwd_reduce_pooled_kernel, dim3(nblk), dim3(256), 0, st, (const float*)p.a2, (const float*)p.da2,
+                           (const float*)p.z2, w->bn_w[1], w->bn_b[1], scale + 32, shift + 32, smean + 32, sinv + 32, p.stats, B, 32,
+                           d.wp1, 64, 16, d.wp2, ppb);
+        else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, st, (const float*)p.z2, (const float*)p.da2,
                            scale + 32, shift + 32, smean + 32, sinv + 32, p.stats, B, 32, d.wp1, 64, 16, d.wp2, ppb);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, nblk, 64,

@@ -711,6 +711,134 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
 }
 
+// The same two sums from the POOLED activations a = pool(relu(bn(z))): dy = da wherever a > 0 (the window's maximum passed
+// the ReLU; a zero gradient otherwise), and at that maximum y = a, hence xhat = (y - beta) / gamma = (a - beta) / gamma.
+// Reads a and da (2 x 52 MB for conv2) instead of z and da (210 + 52 MB).  A channel whose gamma is too small for the
+// division (|gamma| < 1e-2 (1 + |beta|): rounding of a would be amplified) takes the z path for its windows.
+__device__ __forceinline__ bool bn_gamma_ok(float gamma, float beta) { return fabsf(gamma) >= 1e-2f * (1.0f + fabsf(beta)); }
+
+// NHWC activations [B][Hp][Wp][C]; same block / thread mapping and partial layout as bn_bwd_reduce_kernel<false>
+static __global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(
+    const float* __restrict__ a, const float* __restrict__ da, const float* __restrict__ z, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, float2* __restrict__ part, int B, int H, int W, int C, int Hp, int Wp, int pix_per_block) {
+    __shared__ float rs[256], rq[256];
+    const int c4n = C / 4;
+    const int lanes_c = c4n < 64 ? c4n : 64;
+    const int pl = 256 / lanes_c;
+    const int c4 = threadIdx.x % lanes_c, pslot = threadIdx.x / lanes_c;
+    const size_t npix = (size_t)B * Hp * Wp;
+    const size_t p0 = (size_t)blockIdx.x * pix_per_block;
+    for (int cc = c4; cc < c4n; cc += lanes_c) {
+        const float4 gm = *reinterpret_cast<const float4*>(gamma + cc * 4), bt = *reinterpret_cast<const float4*>(beta + cc * 4);
+        const bool fast = bn_gamma_ok(gm.x, bt.x) && bn_gamma_ok(gm.y, bt.y) && bn_gamma_ok(gm.z, bt.z) && bn_gamma_ok(gm.w, bt.w);
+        float4 sdy = make_float4(0.f, 0.f, 0.f, 0.f), sdx = sdy;
+        if (fast) {
+            const float4 rg = make_float4(1.0f / gm.x, 1.0f / gm.y, 1.0f / gm.z, 1.0f / gm.w);
+            for (int i = pslot; i < pix_per_block; i += pl) {
+                const size_t p = p0 + i;
+                if (p >= npix) break;
+                const float4 av = *reinterpret_cast<const float4*>(a + p * C + cc * 4);
+                const float4 g = *reinterpret_cast<const float4*>(da + p * C + cc * 4);
+                const float dx_ = av.x > 0.0f ? g.x : 0.0f, dy_ = av.y > 0.0f ? g.y : 0.0f;
+                const float dz_ = av.z > 0.0f ? g.z : 0.0f, dw_ = av.w > 0.0f ? g.w : 0.0f;
+                sdy.x += dx_; sdy.y += dy_; sdy.z += dz_; sdy.w += dw_;
+                sdx.x = fmaf(dx_, (av.x - bt.x) * rg.x, sdx.x); sdx.y = fmaf(dy_, (av.y - bt.y) * rg.y, sdx.y);
+                sdx.z = fmaf(dz_, (av.z - bt.z) * rg.z, sdx.z); sdx.w = fmaf(dw_, (av.w - bt.w) * rg.w, sdx.w);
+            }
+        } else {
+            const float4 s = *reinterpret_cast<const float4*>(scale + cc * 4), t = *reinterpret_cast<const float4*>(shift + cc * 4);
+            const float4 mu = *reinterpret_cast<const float4*>(mean + cc * 4), is = *reinterpret_cast<const float4*>(invstd + cc * 4);
+            for (int i = pslot; i < pix_per_block; i += pl) {
+                const size_t p = p0 + i;
+                if (p >= npix) break;
+                const int px = p % Wp, py = (p / Wp) % Hp, b = p / ((size_t)Wp * Hp);
+                const float4 g = *reinterpret_cast<const float4*>(da + p * C + cc * 4);
+                float4 zz[4], yy[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    zz[q] = *reinterpret_cast<const float4*>(z + (((size_t)b * H + 2 * py + (q >> 1)) * W + 2 * px + (q & 1)) * C + cc * 4);
+                    yy[q] = make_float4(fmaf(zz[q].x, s.x, t.x), fmaf(zz[q].y, s.y, t.y), fmaf(zz[q].z, s.z, t.z), fmaf(zz[q].w, s.w, t.w));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float dx_ = route1(yy[0].x, yy[1].x, yy[2].x, yy[3].x, q, g.x);
+                    const float dy_ = route1(yy[0].y, yy[1].y, yy[2].y, yy[3].y, q, g.y);
+                    const float dz_ = route1(yy[0].z, yy[1].z, yy[2].z, yy[3].z, q, g.z);
+                    const float dw_ = route1(yy[0].w, yy[1].w, yy[2].w, yy[3].w, q, g.w);
+                    sdy.x += dx_; sdy.y += dy_; sdy.z += dz_; sdy.w += dw_;
+                    sdx.x = fmaf(dx_, (zz[q].x - mu.x) * is.x, sdx.x); sdx.y = fmaf(dy_, (zz[q].y - mu.y) * is.y, sdx.y);
+                    sdx.z = fmaf(dz_, (zz[q].z - mu.z) * is.z, sdx.z); sdx.w = fmaf(dw_, (zz[q].w - mu.w) * is.w, sdx.w);
+                }
+            }
+        }
+        const float vs[4] = {sdy.x, sdy.y, sdy.z, sdy.w}, vq[4] = {sdx.x, sdx.y, sdx.z, sdx.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __syncthreads();
+            rs[threadIdx.x] = vs[e]; rq[threadIdx.x] = vq[e];
+            __syncthreads();
+            if (pslot == 0) {
+                float acc = 0.0f, q2 = 0.0f;
+                for (int k = 0; k < pl; ++k) { acc += rs[k * lanes_c + c4]; q2 += rq[k * lanes_c + c4]; }
+                part[(size_t)blockIdx.x * C + cc * 4 + e] = make_float2(acc, q2);
+            }
+        }
+    }
+}
+
+// GRU-layout activations [B * Wp][C * Hp] with feature = c * Hp + py and C * Hp = 1024, Hp = 8: thread = one float4 of a
+// row (four py of ONE channel), block = rows_per_block rows; lanes 2c, 2c + 1 hold the two halves of channel c.
+static __global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_gru_kernel(
+    const float* __restrict__ a, const float* __restrict__ da, const float* __restrict__ z, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, float2* __restrict__ part, int rows, int H, int W, int Wp, int rows_per_block) {
+    constexpr int C = 128, Hp = 8;
+    const int tid = threadIdx.x, c = tid >> 1, py0 = (tid & 1) * 4;
+    const float gm = gamma[c], bt = beta[c];
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float sdy = 0.0f, sdx = 0.0f;
+    if (bn_gamma_ok(gm, bt)) {
+        const float rg = 1.0f / gm;
+        for (int r = r0; r < r1; ++r) {
+            const float4 av = *reinterpret_cast<const float4*>(a + (size_t)r * 1024 + tid * 4);
+            const float4 g = *reinterpret_cast<const float4*>(da + (size_t)r * 1024 + tid * 4);
+            const float d0 = av.x > 0.0f ? g.x : 0.0f, d1 = av.y > 0.0f ? g.y : 0.0f;
+            const float d2 = av.z > 0.0f ? g.z : 0.0f, d3 = av.w > 0.0f ? g.w : 0.0f;
+            sdy += (d0 + d1) + (d2 + d3);
+            sdx = fmaf(d0, (av.x - bt) * rg, sdx); sdx = fmaf(d1, (av.y - bt) * rg, sdx);
+            sdx = fmaf(d2, (av.z - bt) * rg, sdx); sdx = fmaf(d3, (av.w - bt) * rg, sdx);
+        }
+    } else {
+        const float s = scale[c], t = shift[c], mu = mean[c], is = invstd[c];
+        for (int r = r0; r < r1; ++r) {
+            const int b = r / Wp, px = r - b * Wp;
+            const float4 g4 = *reinterpret_cast<const float4*>(da + (size_t)r * 1024 + tid * 4);
+            const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int py = py0 + e;
+                float zz[4], yy[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    zz[q] = z[(((size_t)b * H + 2 * py + (q >> 1)) * W + 2 * px + (q & 1)) * C + c];
+                    yy[q] = fmaf(zz[q], s, t);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float d_ = route1(yy[0], yy[1], yy[2], yy[3], q, gv[e]);
+                    sdy += d_;
+                    sdx = fmaf(d_, (zz[q] - mu) * is, sdx);
+                }
+            }
+        }
+    }
+    static_assert(C * Hp == 1024, "one 1024-float row per 256 threads");
+    sdy += __shfl_xor(sdy, 1);
+    sdx += __shfl_xor(sdx, 1);
+    if ((tid & 1) == 0) part[(size_t)blockIdx.x * C + c] = make_float2(sdy, sdx);
+}
+
 // sums the (sum dy, sum dy*xhat) partials -> dbeta, dgamma and the two per-channel means used by dz
 static __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float2* __restrict__ part, int nblk, int C, double count,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,

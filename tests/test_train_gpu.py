@@ -257,3 +257,24 @@ def test_gradient_hand_over_matches_autograd_accumulation(sd, monkeypatch):
     train_ops.fused_cross_entropy(m1(x.to(DEV)), y.to(DEV)).backward()
     assert m1.fc.bias.grad is None
     assert torch.equal(m1.fc.weight.grad, ref["fc.weight"])
+
+
+def test_small_bn_gamma_channels_vs_oracle(sd):
+    """The BatchNorm backward sums come from the pooled activations (xhat = (a - beta) / gamma); channels whose gamma is too
+    small for that division -- here exactly zero and 1e-4 in bn2 and bn3 -- must take the z path and still match the oracle."""
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["bn2.weight"][:3] = torch.tensor([0.0, 1e-4, -1e-4])
+    sd2["bn2.bias"][:3] = torch.tensor([0.3, 0.2, 0.1])
+    sd2["bn3.weight"][5:8] = torch.tensor([0.0, 1e-4, -2e-4])
+    sd2["bn3.bias"][5:8] = torch.tensor([0.25, 0.5, 0.05])
+    bsz, t = 6, 200
+    x = cases.varied_features(bsz, t, seed=5)
+    y = synth.synth_labels(bsz, 31, seed=6)
+    m, logits, loss = _hip_step(sd2, x, y)
+    v = _views(m, bsz, t)
+    nchw = lambda a: a.permute(0, 3, 1, 2)
+    ref_loss, ref_grads, _, ref_logits = model_ref.loss_and_grads(sd2, x, y, z_override={2: nchw(v["z2"]), 3: nchw(v["z3"])})
+    assert abs(loss.item() - ref_loss.item()) < 1e-5
+    for name in ("bn2.weight", "bn2.bias", "bn3.weight", "bn3.bias", "conv2.weight", "conv3.weight", "conv1.weight"):
+        e = _rel(dict(m.named_parameters())[name].grad, ref_grads[name])[0]
+        assert e < 2e-3, (name, e)
