@@ -60,3 +60,64 @@ class BatchPipeline:
         if self.n > 1:
             for s in self.streams:
                 self._launch.wait_stream(s)
+
+
+class FeaturePrefetcher:
+    """Feature extraction one batch AHEAD of the training step, on a side stream.
+
+    The features of the NEXT batch depend on nothing in the current training step, so the host->device copy of its
+    waveforms and its feature kernels can be queued early.  (On MI355X at batch 256 with the waveforms already in HBM
+    this is throughput-neutral -- 3.19 vs 3.17 ms per step: the step's kernels leave no idle CUs worth filling -- the
+    point is to take the copy and the feature launch latency off the step's critical path when a loader feeds it.)
+    ``submit(wave, lengths)`` queues the feature kernels of a batch into one of ``depth`` rotating buffers;
+    ``get()`` makes the caller's stream wait for the oldest submitted batch and returns its ``[B, 64, t_pad]``
+    buffer; ``release()`` (call it after the step that consumed the buffer has been queued -- backward reads the
+    features again) lets the side stream overwrite it ``depth`` submissions later.  Values are bit-identical to the
+    in-line ``HipFeaturizer`` call: same kernels, another stream."""
+
+    def __init__(self, t_pad=200, depth=2, **feat_kw):
+        _native.require_hip()
+        self.t_pad, self.depth, self.kw = int(t_pad), max(2, int(depth)), feat_kw
+        self.stream = torch.cuda.Stream()
+        self.fz = HipFeaturizer()
+        self.bufs = [None] * self.depth
+        self.ready = [torch.cuda.Event() for _ in range(self.depth)]
+        self.freed = [None] * self.depth
+        self.head = self.tail = 0              # next slot to fill / next slot to hand out
+        self._out = None
+
+    def submit(self, wave, lengths=None):
+        if self.head - self.tail >= self.depth:
+            raise RuntimeError("FeaturePrefetcher: all buffers are in flight (get() and release() first)")
+        k = self.head % self.depth
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)                        # the waveforms are produced on the caller's stream
+        wave.record_stream(self.stream)
+        if lengths is not None:
+            lengths.record_stream(self.stream)
+        if self.freed[k] is not None:
+            self.stream.wait_event(self.freed[k])           # the step that read this buffer has finished
+        if self.bufs[k] is None or self.bufs[k].shape[0] != wave.shape[0]:
+            self.bufs[k] = torch.empty((wave.shape[0], 64, self.t_pad), dtype=torch.float32, device=wave.device)
+        with torch.cuda.stream(self.stream):
+            self.fz(wave, lengths, t_pad=self.t_pad, out=self.bufs[k], **self.kw)
+            self.ready[k].record(self.stream)
+        self.head += 1
+
+    def get(self):
+        if self.tail >= self.head:
+            raise RuntimeError("FeaturePrefetcher: nothing submitted")
+        k = self.tail % self.depth
+        torch.cuda.current_stream().wait_event(self.ready[k])
+        self._out = k
+        self.tail += 1
+        return self.bufs[k]
+
+    def release(self):
+        """Mark the buffer handed out by the last ``get()`` as consumed by everything queued so far."""
+        if self._out is None:
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.freed[self._out] = ev
+        self._out = None

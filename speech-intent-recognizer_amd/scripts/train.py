@@ -81,6 +81,49 @@ def train_epoch(model, train_loader, optimizer, criterion, device, scaler=None):
     return torch.stack(losses).mean().item()          # one device->host sync per epoch
 
 
+def train_epoch_waveforms(model, wave_loader, optimizer, criterion, device, t_pad=200, augment=None):
+    """``train_epoch`` fed with RAW waveform batches: ``wave_loader`` yields ``(wave [B, L] float32 | int16, lengths int32
+    [B] | None, label int64 [B])``; the log-mel features are computed on the GPU (BASELINE configs[2]: fused HIP feature
+    extraction + forward/backward + Adam) one batch ahead of the training step on a side stream
+    (``sir_amd.pipeline.FeaturePrefetcher``).  ``augment(wave_batch_index, batch_size) -> dict`` may return the
+    featurizer's on-the-fly augmentation arguments (``shift``, ``noise_sigma``, ``noise_seed``, ``time_mask``,
+    ``freq_mask``: scripts/augment.py, dataset.py:160-176) for that batch.  Returns the mean of the per-step losses."""
+    from sir_amd.pipeline import FeaturePrefetcher
+    model.train()
+    loss_fn = _loss_fn(criterion)
+    pre = FeaturePrefetcher(t_pad=t_pad)
+    losses, pending = [], []
+
+    def submit(idx, item):
+        wave, lengths, label = item
+        if wave is None or label is None or wave.size(0) == 0:
+            return
+        wave = wave.to(device, non_blocking=True)
+        lengths = lengths.to(device, non_blocking=True) if lengths is not None else None
+        pre.kw = augment(idx, wave.size(0)) if augment is not None else {}
+        pre.submit(wave, lengths)
+        pending.append(label.to(device, non_blocking=True))
+
+    def step():
+        mel, label = pre.get(), pending.pop(0)
+        optimizer.zero_grad(set_to_none=True)
+        loss = loss_fn(model(mel), label)
+        loss.backward()
+        optimizer.step()
+        pre.release()
+        losses.append(loss.detach())
+
+    for idx, item in enumerate(tqdm(wave_loader, desc="Training", disable=_quiet())):
+        submit(idx, item)
+        if len(pending) == 2:                           # batch idx is queued: train on batch idx - 1 beside it
+            step()
+    while pending:
+        step()
+    if not losses:
+        return 0.0
+    return torch.stack(losses).mean().item()
+
+
 def validate(model, val_loader, criterion, device, scaler=None):
     """(avg_loss, accuracy) over the loader (train.py:120-155); under data parallelism the counts are
     summed over ranks."""

@@ -89,7 +89,9 @@ def test_precompute_dataset_train_evaluate(tmp_path):
         assert list(sd.keys()) == list(synth.synth_state_dict(31).keys())
     else:                                 # the reference only saves on improvement over 0 (train.py:281)
         from sir_amd.models.models import CNNAudioGRU
-        torch.save(CNNAudioGRU(31).state_dict(), ckpt) if not os.path.exists(ckpt) else None
+        if not os.path.exists(ckpt):
+            os.makedirs(cfg["save_path"], exist_ok=True)
+            torch.save(CNNAudioGRU(31).state_dict(), ckpt)
 
     eargs = types.SimpleNamespace(test_csv=csvs["test"], label_map=str(lm), model_path=ckpt)
     acc = ev.evaluate(eargs, cfg)

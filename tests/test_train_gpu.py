@@ -278,3 +278,34 @@ def test_small_bn_gamma_channels_vs_oracle(sd):
     for name in ("bn2.weight", "bn2.bias", "bn3.weight", "bn3.bias", "conv2.weight", "conv3.weight", "conv1.weight"):
         e = _rel(dict(m.named_parameters())[name].grad, ref_grads[name])[0]
         assert e < 2e-3, (name, e)
+
+
+def test_waveform_epoch_with_prefetch_matches_inline_steps(sd):
+    """train_epoch_waveforms (features one batch ahead on a side stream) == features + step in line, bit for bit:
+    same kernels, only the stream changes."""
+    from sir_amd.scripts.train import train_epoch_waveforms
+    nb, bsz = 4, 6
+    waves = [(synth.synth_clips(bsz, 30000 + 1000 * i, seed=40 + i) * 32767).round().to(torch.int16) for i in range(nb)]
+    lens = [torch.tensor([w.shape[1] - 37 * j for j in range(bsz)], dtype=torch.int32) for w in waves]
+    labels = [synth.synth_labels(bsz, 31, seed=50 + i) for i in range(nb)]
+
+    ma = _model(sd)
+    oa = FusedAdam(ma.parameters(), lr=1e-3, weight_decay=1e-4)
+    fz = get_featurizer()
+    ref_losses = []
+    for w, l, y in zip(waves, lens, labels):
+        x = fz(w.to(DEV), l.to(DEV), t_pad=200)
+        oa.zero_grad(set_to_none=True)
+        loss = train_ops.fused_cross_entropy(ma(x), y.to(DEV))
+        loss.backward()
+        oa.step()
+        ref_losses.append(loss.detach())
+    ref_mean = torch.stack(ref_losses).mean().item()
+
+    mb = _model(sd)
+    ob = FusedAdam(mb.parameters(), lr=1e-3, weight_decay=1e-4)
+    mean = train_epoch_waveforms(mb, list(zip(waves, lens, labels)), ob, torch.nn.CrossEntropyLoss(), DEV)
+    torch.cuda.synchronize()
+    assert mean == ref_mean
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.equal(pa, pb), n
