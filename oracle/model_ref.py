@@ -48,19 +48,24 @@ def _bn(x, sd, i, train, new_stats=None):
     return (x - mean[None, :, None, None]) * (inv * g)[None, :, None, None] + b[None, :, None, None]
 
 
-def cnn_stack(x, sd, train=False, new_stats=None, stages=None, z_override=None):
+def cnn_stack(x, sd, train=False, new_stats=None, stages=None, z_override=None, y_override=None):
     """x [B,1,H,W] -> [B,128,H/8,W/8]  (models.py:50-52).
 
     ``z_override`` {block: [B,C,H,W]} substitutes the VALUES of a block's convolution output
     (straight-through: the gradient still flows through the oracle's own convolution).  ReLU and
     max-pool are not differentiable at ties, so two correct fp32 forwards that differ in the last
     bits can route a gradient to different pixels; evaluating the oracle's backward at the device's
-    forward values removes that ambiguity from a backward parity check."""
+    forward values removes that ambiguity from a backward parity check.
+    ``y_override`` {block: [B,C,H,W]} does the same for the BatchNorm OUTPUT (the values ReLU and the
+    pooling actually compare): with the device's z alone, the oracle's own rounding of scale / shift can
+    still break a near-tie the other way."""
     for i in (1, 2, 3):
         x = F.conv2d(x, sd[f"conv{i}.weight"], bias=None, stride=1, padding=1)
         if z_override is not None and i in z_override:
             x = x + (z_override[i] - x).detach()
         x = _bn(x, sd, i, train, new_stats)
+        if y_override is not None and i in y_override:
+            x = x + (y_override[i] - x).detach()
         x = F.max_pool2d(torch.relu(x), 2)
         if stages is not None:
             stages[f"conv{i}"] = x
@@ -102,11 +107,11 @@ def bigru(x, sd, dropout_mask=None, stages=None):
     return x
 
 
-def forward(sd, x, train=False, new_stats=None, dropout_mask=None, stages=None, z_override=None):
+def forward(sd, x, train=False, new_stats=None, dropout_mask=None, stages=None, z_override=None, y_override=None):
     """x [B,64,T] or [B,1,64,T] -> logits [B,C]  (models.py:41-68)."""
     if x.dim() == 3:
         x = x.unsqueeze(1)
-    x = cnn_stack(x, sd, train, new_stats, stages, z_override)
+    x = cnn_stack(x, sd, train, new_stats, stages, z_override, y_override)
     b, c, h, w = x.shape
     seq = x.permute(0, 3, 1, 2).contiguous().view(b, w, c * h)     # feature = c*h_dim + h
     if stages is not None:
@@ -122,7 +127,7 @@ def forward(sd, x, train=False, new_stats=None, dropout_mask=None, stages=None, 
     return ctx @ sd["fc.weight"].t() + sd["fc.bias"]
 
 
-def loss_and_grads(sd, x, labels, dropout_mask=None, stages=None, z_override=None):
+def loss_and_grads(sd, x, labels, dropout_mask=None, stages=None, z_override=None, y_override=None):
     """One training-mode forward/backward (CE mean).  Returns loss, grads{key}, new BN stats, logits.
     With ``stages`` (a dict) the intermediate activations are stored under their names and their
     gradients under ``"d_" + name`` (for stage-level checks of the HIP backward)."""
@@ -131,7 +136,7 @@ def loss_and_grads(sd, x, labels, dropout_mask=None, stages=None, z_override=Non
     full.update(params)
     new_stats = {}
     logits = forward(full, x, train=True, new_stats=new_stats, dropout_mask=dropout_mask, stages=stages,
-                     z_override=z_override)
+                     z_override=z_override, y_override=y_override)
     if stages is not None:
         for t in stages.values():
             t.retain_grad()

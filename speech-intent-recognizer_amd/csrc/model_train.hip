@@ -23,6 +23,7 @@ enum TrainBuf {
     TB_WCB,       // bf16x3 conv weights: conv2, conv3 forward, then conv2, conv3 data-gradient forms
     TB_GXB,       // paired GRU exchange granules
     TB_GFL,       // paired GRU status word
+    TB_C1M,       // conv1 input moments: 54 doubles (conv1_moments_kernel), forward -> backward
     TB_COUNT
 };
 
@@ -101,7 +102,7 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     n[TB_DA2] = n[TB_A2];
     n[TB_DZ2] = n[TB_Z2];
     n[TB_DA1] = n[TB_A1];
-    n[TB_SMALL] = B * 512 + B + 64 + (size_t)d.c1gx * d.c1gy * B * 288;
+    n[TB_SMALL] = B * 512 + B + 64 + (size_t)d.c1gx * d.c1gy * B * 352;      // conv1 backward partials: 32 x 11 per block
     size_t slab = (size_t)d.wg3_blocks * 9 * 128 * 64;
     const size_t s_w2 = (size_t)d.wg2_blocks * wgrad_x6_ksplit(32, 64) * 9 * 64 * 32, s_g = (size_t)d.ksplits * 768 * 1024;
     if (s_w2 > slab) slab = s_w2;
@@ -118,6 +119,7 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     n[TB_WCB] = ((size_t)2 * (3 * 32 * 9 * 64 + 3 * 64 * 9 * 128) + 1) / 2;
     n[TB_GXB] = sir_gru_pair_xbuf_bytes(d.B) / 4;
     n[TB_GFL] = sir_gru_pair_flag_bytes(d.B) / 4;
+    n[TB_C1M] = 2 * C1_NMOM;
 }
 
 size_t tws_layout(const TDims& d, size_t* off) {
@@ -133,6 +135,8 @@ size_t tws_layout(const TDims& d, size_t* off) {
 const int kBnC[3] = {32, 64, 128}, kBnO[3] = {0, 32, 96};
 // BatchNorm backward sums from the pooled activations (bn_bwd_reduce_pooled_kernel) instead of the raw conv outputs
 const int bn_reduce_pooled = getenv("SIR_BN_REDUCE_POOLED") ? atoi(getenv("SIR_BN_REDUCE_POOLED")) : 1;
+// conv1 BatchNorm statistics and the mean terms of its weight gradient from 54 moments of the input (conv1_moments_kernel)
+const int conv1_moments = getenv("SIR_CONV1_MOMENTS") ? atoi(getenv("SIR_CONV1_MOMENTS")) : 1;
 
 #define KCHECK() SIR_HIP_TRY(hipGetLastError())
 
@@ -143,6 +147,7 @@ struct TPtrs {
     unsigned short *xs, *wsl0, *wsl1, *wcb2, *wcb3, *wcb2t, *wcb3t;
     float* gxb;
     unsigned int* gfl;
+    double* c1m;
 };
 
 TPtrs carve(void* ws, const size_t* off) {
@@ -164,6 +169,7 @@ TPtrs carve(void* ws, const size_t* off) {
     p.wcb2 = (unsigned short*)(b + off[TB_WCB]); p.wcb3 = p.wcb2 + (size_t)3 * 32 * 9 * 64;
     p.wcb2t = p.wcb3 + (size_t)3 * 64 * 9 * 128; p.wcb3t = p.wcb2t + (size_t)3 * 32 * 9 * 64;
     p.gxb = (float*)(b + off[TB_GXB]); p.gfl = (unsigned int*)(b + off[TB_GFL]);
+    p.c1m = (double*)(b + off[TB_C1M]);
     return p;
 }
 
@@ -244,10 +250,21 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     // conv1 block: statistics pass (recompute), finalize, then the fused conv+BN+ReLU+pool pass
     {
         const dim3 g1(d.c1gx, d.c1gy, B);
+        if (conv1_moments) {                           // statistics from 54 moments of the input, no conv1 recompute
+            const int tiles = d.c1gx * d.c1gy;
+            int per_img = (2048 + B - 1) / B;             // workgroups per image: >= 2048 in all when the batch allows it
+            per_img = per_img < 1 ? 1 : (per_img > tiles ? tiles : per_img);
+            hipLaunchKernelGGL(conv1_moments_kernel, dim3(per_img, B), dim3(256), 0, st, feats, (float*)p.stats, 64, T, d.c1gx, d.c1gy);
+            hipLaunchKernelGGL(conv1_moments_reduce_kernel, dim3(C1_NMOM), dim3(256), 0, st, (const float*)p.stats, per_img * B, p.c1m);
+            hipLaunchKernelGGL(conv1_bn_from_moments_kernel, dim3(1), dim3(64), 0, st, (const double*)p.c1m, w->conv_w[0],
+                               (double)B * 64 * T, w->bn_w[0], w->bn_b[0], bn_running_mean[0], bn_running_var[0], bn_momentum,
+                               scale, shift, smean, sinv);
+        } else {
         hipLaunchKernelGGL(conv1_stats_kernel, g1, dim3(256), 0, st, feats, w->conv_w[0], p.stats, 64, T);
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(32), dim3(256), 0, st, (const float2*)p.stats, d.c1gx * d.c1gy * B, 32,
                            (double)B * 64 * T, w->bn_w[0], w->bn_b[0], bn_running_mean[0], bn_running_var[0], bn_momentum,
                            scale, shift, smean, sinv);
+        }
         hipLaunchKernelGGL(conv1_bn_relu_pool_kernel, dim3((d.wp1 + C1_PCOLS - 1) / C1_PCOLS, d.c1gy, B), dim3(256), 0, st,
                            feats, w->conv_w[0], scale, shift, p.a1, 64, T, 32, d.wp1);
     }
@@ -611,11 +628,25 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
     {
         const dim3 g1(d.c1gx, d.c1gy, B);
         const int nblk = d.c1gx * d.c1gy * B;
-        hipLaunchKernelGGL(conv1_bwd_kernel<false>, g1, dim3(256), 0, st, feats, w->conv_w[0], (const float*)p.da1, scale, shift,
+        if (conv1_moments) {
+            // one recompute pass: (sum dy, sum dy*xhat, sum dy*x_tap) per channel; the rest of dW1 is closed form in the moments
+            hipLaunchKernelGGL(conv1_bwd_kernel<2>, g1, dim3(256), 0, st, feats, w->conv_w[0], (const float*)p.da1, scale, shift,
+                               smean, sinv, (const float*)nullptr, (const float*)nullptr, c1part, 64, T, 32, d.wp1);
+            float* c1tmp = (float*)p.stats;           // [128][352] partial column sums, then [352] totals behind them
+            float* c1tot = c1tmp + 128 * 352;
+            hipLaunchKernelGGL(colsum_partial_kernel, dim3((352 + 63) / 64, 128), dim3(256), 0, st, (const float*)c1part, nblk, 352,
+                               352, c1tmp);
+            hipLaunchKernelGGL(colsum_kernel, dim3((352 + 63) / 64), dim3(256), 0, st, (const float*)c1tmp, 128, 352, 352, c1tot);
+            hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(320), 0, st, (const float*)c1tot, (const double*)p.c1m,
+                               w->conv_w[0], scale, smean, sinv, (double)B * 64 * T, g->bn_w[0], g->bn_b[0], g->conv_w[0]);
+            KCHECK();
+            return SIR_OK;
+        }
+        hipLaunchKernelGGL(conv1_bwd_kernel<0>, g1, dim3(256), 0, st, feats, w->conv_w[0], (const float*)p.da1, scale, shift,
                            smean, sinv, (const float*)nullptr, (const float*)nullptr, (float*)p.stats, 64, T, 32, d.wp1);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(32), dim3(256), 0, st, (const float2*)p.stats, nblk, 32, (double)B * 64 * T,
                            g->bn_w[0], g->bn_b[0], mdy, mdyx);
-        hipLaunchKernelGGL(conv1_bwd_kernel<true>, g1, dim3(256), 0, st, feats, w->conv_w[0], (const float*)p.da1, scale, shift,
+        hipLaunchKernelGGL(conv1_bwd_kernel<1>, g1, dim3(256), 0, st, feats, w->conv_w[0], (const float*)p.da1, scale, shift,
                            smean, sinv, (const float*)mdy, (const float*)mdyx, c1part, 64, T, 32, d.wp1);
         float* c1tmp = (float*)p.stats;               // [128][288], the BN partials are consumed by now
         hipLaunchKernelGGL(colsum_partial_kernel, dim3((288 + 63) / 64, 128), dim3(256), 0, st, (const float*)c1part, nblk, 288,

@@ -61,6 +61,131 @@ static __global__ __launch_bounds__(256) void conv1_stats_kernel(const float* __
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// conv1 BatchNorm statistics WITHOUT computing conv1: z_c = sum_t w_c[t] x_t with x_t the nine shifted copies of the
+// (zero-padded) feature image, hence
+//     sum z_c   = sum_t w_c[t] S[t]                       S[t]     = sum_pixels x_t
+//     sum z_c^2 = sum_{t,u} w_c[t] w_c[u] R[t][u]         R[t][u]  = sum_pixels x_t x_u
+// -- 9 + 45 moments of the INPUT, the same for all 32 channels (one pass over 13 MB instead of recomputing 105 M conv
+// outputs x 32 channels).  The backward reuses them for the mean terms of the weight gradient (conv1_bwd_finalize_kernel).
+// Moment layout M[54]: S[0..8], then R packed by rows, t <= u: index 9 + t*9 - t*(t-1)/2 + (u - t).
+// ------------------------------------------------------------------------------------------
+constexpr int C1_NMOM = 54;
+__host__ __device__ constexpr int c1_r_index(int t, int u) { return 9 + t * 9 - t * (t - 1) / 2 + (u - t); }   // t <= u
+
+// wave WV of a block accumulates the moments [14 WV, 14 WV + 14) -- over ALL pixels of a tile -- so that each of the 54 sums
+// is reduced across 64 lanes exactly once per block (with 54 accumulators in every thread the wave reductions cost more than
+// the accumulation itself)
+constexpr int C1_MPW = 14;
+template <int WV>
+__device__ __forceinline__ void c1_moments_accum(const float (&v)[9], float (&m)[C1_MPW]) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (t / C1_MPW == WV) m[t - C1_MPW * WV] += v[t];
+#pragma unroll
+        for (int u = t; u < 9; ++u)
+            if (c1_r_index(t, u) / C1_MPW == WV) m[c1_r_index(t, u) - C1_MPW * WV] = fmaf(v[t], v[u], m[c1_r_index(t, u) - C1_MPW * WV]);
+    }
+}
+
+// block (g, b) walks the 8 x 64-pixel tiles g, g + gridDim.x, ... of image b; part[b * gridDim.x + g][54]
+static __global__ __launch_bounds__(256) void conv1_moments_kernel(const float* __restrict__ x, float* __restrict__ part, int H, int W,
+                                                                    int tiles_x, int tiles_y) {
+    __shared__ float tile[C1_TR * C1_TC];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* xb = x + (size_t)b * H * W;
+    float m[C1_MPW];
+#pragma unroll
+    for (int i = 0; i < C1_MPW; ++i) m[i] = 0.0f;
+    for (int tl = blockIdx.x; tl < tiles_x * tiles_y; tl += gridDim.x) {
+        const int y0 = 2 * (tl / tiles_x) * C1_PROWS, x0 = 2 * (tl % tiles_x) * C1_PCOLS;
+        __syncthreads();                                   // previous tile consumed
+        for (int i = tid; i < C1_TR * C1_TC; i += 256) {
+            const int ty = i / C1_TC, tx = i - ty * C1_TC;
+            const int gy = y0 - 1 + ty, gx = x0 - 1 + tx;
+            tile[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xb[(size_t)gy * W + gx] : 0.0f;
+        }
+        __syncthreads();
+        for (int k = 0; k < (4 * C1_PROWS * C1_PCOLS) / 64; ++k) {          // 512 pixels / 64 lanes
+            const int pix = lane + 64 * k, ly = pix / (2 * C1_PCOLS), lx = pix % (2 * C1_PCOLS);
+            if (y0 + ly >= H || x0 + lx >= W) continue;
+            float v[9];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) v[ky * 3 + kx] = tile[(ly + ky) * C1_TC + lx + kx];
+            switch (wv) {                                   // wave-uniform
+                case 0: c1_moments_accum<0>(v, m); break;
+                case 1: c1_moments_accum<1>(v, m); break;
+                case 2: c1_moments_accum<2>(v, m); break;
+                default: c1_moments_accum<3>(v, m); break;
+            }
+        }
+    }
+    const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < C1_MPW; ++i) {
+        float a = m[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0 && C1_MPW * wv + i < C1_NMOM) part[blk * C1_NMOM + C1_MPW * wv + i] = a;
+    }
+}
+
+// M[i] = sum over blocks (double); one block per moment
+static __global__ __launch_bounds__(256) void conv1_moments_reduce_kernel(const float* __restrict__ part, int nblk, double* __restrict__ M) {
+    __shared__ double rs[256];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0;
+    for (int r = tid; r < nblk; r += 256) s += part[(size_t)r * C1_NMOM + i];
+    rs[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) rs[tid] += rs[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) M[i] = rs[0];
+}
+
+__device__ __forceinline__ void bn_finalize_channel(double sum, double sumsq, double count, int c, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                    float* __restrict__ run_var, float momentum, float* __restrict__ scale,
+                                                    float* __restrict__ shift, float* __restrict__ save_mean,
+                                                    float* __restrict__ save_invstd) {
+    const double mean = sum / count;
+    double var = sumsq / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)SIR_BN_EPS));
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = invstd;
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mean;
+    run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unbiased;
+}
+
+// per channel: (sum z, sum z^2) from the moments and the nine weights, then the usual BatchNorm finalisation; 32 threads
+static __global__ void conv1_bn_from_moments_kernel(const double* __restrict__ M, const float* __restrict__ w, double count,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float* __restrict__ run_mean, float* __restrict__ run_var, float momentum,
+                                                    float* __restrict__ scale, float* __restrict__ shift,
+                                                    float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    const int c = threadIdx.x;
+    if (c >= 32) return;
+    double wk[9];
+    for (int t = 0; t < 9; ++t) wk[t] = (double)w[c * 9 + t];
+    double sum = 0.0, sumsq = 0.0;
+    for (int t = 0; t < 9; ++t) {
+        sum += wk[t] * M[t];
+        sumsq += wk[t] * wk[t] * M[c1_r_index(t, t)];
+        for (int u = t + 1; u < 9; ++u) sumsq += 2.0 * wk[t] * wk[u] * M[c1_r_index(t, u)];
+    }
+    bn_finalize_channel(sum, sumsq, count, c, gamma, beta, run_mean, run_var, momentum, scale, shift, save_mean, save_invstd);
+}
+
 // partial (sum, sumsq) [nblk][C] -> batch mean / biased var -> folded scale/shift for the forward,
 // saved mean / invstd for the backward, running statistics updated in place
 // (momentum 0.1, unbiased variance: torch.nn.BatchNorm2d training semantics).  One block per channel.
@@ -84,20 +209,8 @@ static __global__ __launch_bounds__(256) void bn_finalize_kernel(const float2* _
         if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
         __syncthreads();
     }
-    if (tid == 0) {
-        const double mean = rs[0] / count;
-        double var = rq[0] / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)SIR_BN_EPS));
-        const float sc = gamma[c] * invstd;
-        scale[c] = sc;
-        shift[c] = beta[c] - (float)mean * sc;
-        save_mean[c] = (float)mean;
-        save_invstd[c] = invstd;
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mean;
-        run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unbiased;
-    }
+    if (tid == 0)
+        bn_finalize_channel(rs[0], rq[0], count, c, gamma, beta, run_mean, run_var, momentum, scale, shift, save_mean, save_invstd);
 }
 
 // z (raw conv output, NHWC [B][H][W][C]) -> relu(bn(z)) -> 2x2 max-pool.
@@ -926,14 +1039,18 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const float* __restrict_
 //   pass 2: dz = gamma*invstd*(dy - mean dy - xhat*mean(dy xhat)), dW1[c][tap] partials per block
 // Same tiling as conv1_bn_relu_pool_kernel: block = 4 x 32 pooled pixels, lane&31 = channel.
 // ------------------------------------------------------------------------------------------
-template <bool WGRAD>
+// MODE 0: pass 1;  MODE 1: pass 2 (needs mdy / mdyx);  MODE 2: both in ONE pass -- (sum dy, sum dy*xhat, A[9]) with
+// A[tap] = sum dy * x_tap, the only data-dependent part of the weight gradient: the mean terms of dz are closed forms in the
+// input moments of conv1_moments_kernel (conv1_bwd_finalize_kernel).
+template <int MODE>
 __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ da, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ mdy,
                                                          const float* __restrict__ mdyx, float* __restrict__ part,
                                                          int H, int W, int Hp, int Wp) {
-    constexpr int NV = WGRAD ? 9 : 2;
+    constexpr bool WGRAD = MODE == 1;
+    constexpr int NV = MODE == 0 ? 2 : (MODE == 1 ? 9 : 11);
     __shared__ float tile[C1_TR * C1_TC];
     __shared__ float red[8 * 32 * NV];
     const int b = blockIdx.z, py0 = blockIdx.y * C1_PROWS, px0 = blockIdx.x * C1_PCOLS;
@@ -981,9 +1098,20 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
             if (gy >= H || gx >= W) continue;
             const float dyq = pooled ? route1(yv[0], yv[1], yv[2], yv[3], q, g) : 0.0f;
             const float xh = (a[q] - mu) * is;
-            if (!WGRAD) {
+            if (MODE != 1) {
                 accv[0] += dyq;
                 accv[1] = fmaf(dyq, xh, accv[1]);
+                if (MODE == 2) {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            accv[2 + ky * 3 + kx] = fmaf(dyq, in[(q >> 1) + ky][(q & 1) + kx], accv[2 + ky * 3 + kx]);
+                            // keeps the SLP vectoriser from pairing these into v_pk_fma_f32: the shifted windows are not
+                            // register-pair aligned, and the pairing cost 160 v_mov per pixel (166 us instead of ~100)
+                            asm volatile("" : "+v"(accv[2 + ky * 3 + kx]));
+                        }
+                }
             } else {
                 const float dzq = s * (dyq - m1 - xh * m2);
 #pragma unroll
@@ -1004,6 +1132,26 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
         for (int k = 0; k < 8; ++k) v += red[k * 32 * NV + o];
         part[blk * 32 * NV + o] = v;           // !WGRAD: float2 (sum dy, sum dy xhat) per channel
     }
+}
+
+// totals[c][11] = (sum dy, sum dy*xhat, A[9]) summed over the blocks;  M = input moments (forward).  Thread (c, tap):
+//   dW[c][tap] = s_c (A[tap] - m1 S[tap] - m2 invstd_c (sum_t w_c[t] R[t][tap] - mean_c S[tap])),   m1 = sum dy / N, m2 = sum dy*xhat / N
+// (dz = s (dy - m1 - xhat m2), xhat = (z - mean) invstd, z = sum_t w[t] x_t), evaluated in double; thread (c, 0) also writes
+// dbeta = sum dy and dgamma = sum dy*xhat.
+static __global__ void conv1_bwd_finalize_kernel(const float* __restrict__ totals, const double* __restrict__ M, const float* __restrict__ w,
+                                                 const float* __restrict__ scale, const float* __restrict__ mean,
+                                                 const float* __restrict__ invstd, double count, float* __restrict__ dgamma,
+                                                 float* __restrict__ dbeta, float* __restrict__ dw) {
+    const int idx = threadIdx.x;
+    if (idx >= 288) return;
+    const int c = idx / 9, tap = idx % 9;
+    const double sdy = totals[c * 11], sdx = totals[c * 11 + 1], A = totals[c * 11 + 2 + tap];
+    const double m1 = sdy / count, m2 = sdx / count;
+    double zx = 0.0;                                             // sum z * x_tap
+    for (int t = 0; t < 9; ++t) zx += (double)w[c * 9 + t] * M[t <= tap ? c1_r_index(t, tap) : c1_r_index(tap, t)];
+    const double xhx = (double)invstd[c] * (zx - (double)mean[c] * M[tap]);
+    dw[c * 9 + tap] = (float)((double)scale[c] * (A - m1 * M[tap] - m2 * xhx));
+    if (tap == 0) { dbeta[c] = (float)sdy; dgamma[c] = (float)sdx; }
 }
 
 // ------------------------------------------------------------------------------------------
