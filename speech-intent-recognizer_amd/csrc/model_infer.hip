@@ -94,6 +94,11 @@ int sir_gru_variant() {      // 0 = streaming fp32 kernel, 1 = paired fp32 kerne
     return v;
 }
 
+int sir_conv1_mfma() {
+    static const int v = getenv("SIR_CONV1_MFMA") ? atoi(getenv("SIR_CONV1_MFMA")) : 1;
+    return v;
+}
+
 int sir_conv_ns() {
     static const int v = getenv("SIR_CONV_NS") ? atoi(getenv("SIR_CONV_NS")) : 1;
     return v;
@@ -192,7 +197,8 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
 
     // ---- CNN stack ------------------------------------------------------------------------
     { SirProfScope prof(h, SIR_K_CONV1, st);
-    hipLaunchKernelGGL(conv1_bn_relu_pool_kernel, dim3((d.wp1 + C1_PCOLS - 1) / C1_PCOLS, (32 + C1_PROWS - 1) / C1_PROWS, B),
+    hipLaunchKernelGGL(sir_conv1_mfma() ? conv1_mfma_bn_relu_pool_kernel : conv1_bn_relu_pool_kernel,
+                       dim3((d.wp1 + C1_PCOLS - 1) / C1_PCOLS, sir_conv1_mfma() ? 1 : (32 + C1_PROWS - 1) / C1_PROWS, B),
                        dim3(256), 0, st, feats, w->conv_w[0], bns, bnt, a1, 64, d.T, 32, d.wp1); }
     static const int conv2_variant = getenv("SIR_CONV2_VARIANT") ? atoi(getenv("SIR_CONV2_VARIANT")) : 0;   // A/B switch
     {

@@ -97,6 +97,96 @@ static __global__ __launch_bounds__(256) void conv1_bn_relu_pool_kernel(
     }
 }
 
+// The same block on the f32 matrix pipe: the direct form above is bound by VALU issue (36 FMAs per output), and
+// v_mfma_f32_32x32x2_f32 does 2048 of them per instruction at the packed-f32 vector rate while the VALU is free for the
+// BN / ReLU / pooling epilogue.  GEMM view: D[channel i][pixel j] = sum_tap w[i][tap] x_tap[j], K = 9 taps padded to 10
+// (five K = 2 steps; exact f32, an fmaf chain over the taps in order -- the same arithmetic as the direct form).
+//   A operand (lane l): w[l & 31][2 s + (l >> 5)], five registers for the whole block;
+//   B operand (lane l): tile[(row + ky) * C1_TC + col0 + (l & 31) + kx] for tap = 2 s + (l >> 5): one ds_read_b32;
+//   D: lane l holds pixel l & 31, channels (r & 3) + 8 (r >> 2) + 4 (l >> 5), r = 0..15.
+// Wave w = pooled row w of the 4 x 32 pooled-pixel block; per half (32 conv columns) two accumulators (the two conv rows
+// of the pooled row); 2x2 max = max of the two accumulators and of lanes j, j ^ 1.  Even lanes then store channel groups
+// 0, 1 and odd lanes groups 2, 3 of pooled pixel j / 2 (two float4 stores per lane).
+static __global__ __launch_bounds__(256) void conv1_mfma_bn_relu_pool_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp) {
+    // One block walks ALL row tiles of its column strip (grid = (column strips, 1, B)): weights / scale / shift are
+    // loaded once, and the next tile's pixels are fetched into registers while the matrix pipe works on the current one
+    // (one short block per tile spent most of its life waiting for its own loads: 50 us for 17 us of MFMA work).
+    __shared__ float tiles[2][C1_TR * C1_TC];
+    const int b = blockIdx.z, px0 = blockIdx.x * C1_PCOLS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, kh = lane >> 5;
+    const float* xb = x + (size_t)b * H * W;
+    constexpr int NPRE = (C1_TR * C1_TC + 255) / 256;
+    float pre[NPRE];
+    auto fetch = [&](int py0) {
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            const int i = tid + 256 * q, ty = i / C1_TC, tx = i - ty * C1_TC;
+            const int gy = 2 * py0 - 1 + ty, gx = 2 * px0 - 1 + tx;
+            pre[q] = (i < C1_TR * C1_TC && gy >= 0 && gy < H && gx >= 0 && gx < W) ? xb[(size_t)gy * W + gx] : 0.0f;
+        }
+    };
+    fetch(0);
+    float wa[5];
+    int boff[5];                                            // tile offset of this lane's tap in step s
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int tap = 2 * s + kh;
+        wa[s] = tap < 9 ? w[j * 9 + tap] : 0.0f;            // j doubles as the channel index i of the A operand
+        const int tc = tap < 9 ? tap : 8;
+        boff[s] = (tc / 3) * C1_TC + (tc % 3) + j;
+    }
+    float sc[16], sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        sc[r] = scale[ch]; sh[r] = shift[ch];
+    }
+    const bool odd = j & 1;                                  // even lanes store channel groups 0, 1; odd lanes groups 2, 3
+    int it = 0;
+    for (int py0 = 0; py0 < Hp; py0 += C1_PROWS, ++it) {
+        float* tile = tiles[it & 1];
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q)
+            if (tid + 256 * q < C1_TR * C1_TC) tile[tid + 256 * q] = pre[q];
+        __syncthreads();                                     // (the other buffer was last read before the previous barrier)
+        if (py0 + C1_PROWS < Hp) fetch(py0 + C1_PROWS);
+        const int py = py0 + wv;
+        if (py >= Hp) continue;
+        const float* trow = tile + (2 * wv) * C1_TC;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (px0 + 16 * h >= Wp) break;                   // the last strip of a 100-column image has 4 valid columns
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                const float b0 = trow[boff[s] + 32 * h], b1 = trow[boff[s] + 32 * h + C1_TC];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s], b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s], b1, acc1, 0, 0, 0);
+            }
+            float m[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = fmaxf(fmaf(acc0[r], sc[r], sh[r]), fmaf(acc1[r], sc[r], sh[r]));
+                // neighbouring pixel = lane ^ 1: quad_perm(1, 0, 3, 2) on the DPP path (no LDS round trip)
+                const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+                m[r] = fmaxf(fmaxf(v, nb), 0.0f);
+            }
+            const int px = px0 + 16 * h + (j >> 1);
+            const float4 lo = odd ? make_float4(m[8], m[9], m[10], m[11]) : make_float4(m[0], m[1], m[2], m[3]);
+            const float4 hi = odd ? make_float4(m[12], m[13], m[14], m[15]) : make_float4(m[4], m[5], m[6], m[7]);
+            if (px < Wp) {
+                float* o = out + (((size_t)b * Hp + py) * Wp + px) * 32 + 4 * kh + (odd ? 16 : 0);
+                *reinterpret_cast<float4*>(o) = lo;
+                *reinterpret_cast<float4*>(o + 8) = hi;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // conv 3x3 (CIN -> COUT) + BN + ReLU + 2x2 max-pool as an implicit GEMM on fp32 MFMA.
 //   M = pixels (A operand, from an NHWC input tile with halo staged in LDS),

@@ -265,7 +265,8 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
                            (double)B * 64 * T, w->bn_w[0], w->bn_b[0], bn_running_mean[0], bn_running_var[0], bn_momentum,
                            scale, shift, smean, sinv);
         }
-        hipLaunchKernelGGL(conv1_bn_relu_pool_kernel, dim3((d.wp1 + C1_PCOLS - 1) / C1_PCOLS, d.c1gy, B), dim3(256), 0, st,
+        hipLaunchKernelGGL(sir_conv1_mfma() ? conv1_mfma_bn_relu_pool_kernel : conv1_bn_relu_pool_kernel,
+                           dim3((d.wp1 + C1_PCOLS - 1) / C1_PCOLS, sir_conv1_mfma() ? 1 : d.c1gy, B), dim3(256), 0, st,
                            feats, w->conv_w[0], scale, shift, p.a1, 64, T, 32, d.wp1);
     }
     // conv2 block: raw conv + partial statistics on MFMA, finalize, BN+ReLU+pool

@@ -112,5 +112,7 @@ int sir_gru_variant();
 // paired-workgroup GRU backward recurrence (gru_pair.hip); SIR_GRU_BWD_VARIANT=0 selects the streaming kernel
 int sir_launch_gru_bwd_pair(hipStream_t st, const float* dy, const float* gates, const float* y, const float* whh0, const float* whh1,
                             float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S, float* xbuf, unsigned int* flags);
+// conv1 on the f32 matrix pipe (SIR_CONV1_MFMA, default 1) instead of the direct VALU form
+int sir_conv1_mfma();
 // convolution generation (SIR_CONV_NS, default 1 = output channels split over the waves)
 int sir_conv_ns();
