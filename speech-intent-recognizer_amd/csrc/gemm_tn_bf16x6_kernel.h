@@ -9,6 +9,10 @@
 // One launch covers up to four jobs (both directions x {W_ih, W_hh} of a layer): blockIdx.x walks the 128 x 256 output
 // tiles of all jobs, blockIdx.y the K splits; every (tile, split) writes its partial to the job's slab z (deterministic
 // slab_reduce afterwards).  8 waves, wave tile 64 x 64 (2 x 2 accumulators), 24 MFMAs per 16-token step.
+// Tried and removed: 16-token stages in two LDS buffers with the next stage's transposing stores placed between the MFMAs
+// (sched_group_barrier 2 MFMA : 10 VALU : 3 LDS stores) and one barrier per stage -- 153-158 us against 140 us for the
+// dW launch and 167-178 against 147 us for dX: the 48-byte rows make the 2-byte stores 2-way bank-conflicted and the
+// shorter MFMA runs between barriers expose more latency than the overlap hides.
 //   seq / shift: row tok of B is taken from row tok + shift of the same length-`seq` sequence, zero outside it (the
 //   h_{t-1} / h_{t+1} operand of the W_hh gradient), as in gemm_general_kernel.
 #pragma once
