@@ -215,7 +215,7 @@ def test_loss_decreases_with_dropout_and_full_batch(sd):
     assert torch.isfinite(m(x)).all()
 
 
-@pytest.mark.parametrize("bsz,t", [(5, 96), (18, 200)])
+@pytest.mark.parametrize("bsz,t", [(5, 96), (18, 200), (3, 94), (2, 61)])
 def test_ragged_training_step_vs_oracle(sd, bsz, t):
     """Backward parity at batch sizes that leave GRU groups / pairs partly empty and at a shorter sequence."""
     x = cases.varied_features(bsz, t, seed=77 + bsz)
