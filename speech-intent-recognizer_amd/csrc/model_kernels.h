@@ -656,34 +656,59 @@ static __global__ __launch_bounds__(256) void attention_pool_kernel(const float*
     float a[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) a[i] = aw[lane + 64 * i];
-    for (int t = wv; t < S; t += 4) {
-        float d = 0.0f;
+    // four time steps per wave and round with all 32 loads issued before the first reduction (one step at a time, the
+    // seven dependent load -> reduce rounds of a wave were half of this kernel's time)
+    for (int t0 = 4 * wv; t0 < S; t0 += 16) {
+        float v[4][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) d = fmaf(yb[(size_t)t * 512 + lane + 64 * i], a[i], d);
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
-        if (lane == 0) sc[t] = d + ab[0];
+            for (int i = 0; i < 8; ++i) v[k][i] = (t0 + k < S) ? yb[(size_t)(t0 + k) * 512 + lane + 64 * i] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float d = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d = fmaf(v[k][i], a[i], d);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+            if (lane == 0 && t0 + k < S) sc[t0 + k] = d + ab[0];
+        }
     }
     __syncthreads();
+    // softmax weights once per time step (thread t), not once per (channel, time step): the exponentials were 5000
+    // instructions per thread and most of this kernel's 21 us
+    __shared__ float ex[ATT_MAX_S];
     float mx = -INFINITY;
     for (int t = 0; t < S; ++t) mx = fmaxf(mx, sc[t]);
+    if (tid < S) ex[tid] = expf(sc[tid] - mx);
+    __syncthreads();
     float den = 0.0f;
-    for (int t = 0; t < S; ++t) den += expf(sc[t] - mx);
+    for (int t = 0; t < S; ++t) den += ex[t];
+    __syncthreads();                                          // every thread has read ex[] before it is overwritten
+    if (tid < S) ex[tid] = ex[tid] / den;
+    __syncthreads();
     for (int c = tid; c < 512; c += 256) {
         float acc = 0.0f;
-        for (int t = 0; t < S; ++t) acc = fmaf(expf(sc[t] - mx) / den, yb[(size_t)t * 512 + c], acc);
+        for (int t = 0; t < S; ++t) acc = fmaf(ex[t], yb[(size_t)t * 512 + c], acc);
         ctx[(size_t)b * 512 + c] = acc;
         cs[c] = acc;
     }
     if (!logits) return;
     __syncthreads();
-    for (int j = wv; j < C; j += 4) {
+    // classifier: thread = (class j = tid / 8 (+ 32), eighth of the 512 inputs); sixteen independent float4 loads per thread,
+    // then a reduction over the eight lanes of a class (C <= 64)
+    for (int j = tid >> 3; j < C; j += 32) {
+        const int part = tid & 7;
+        const float4* wr = reinterpret_cast<const float4*>(fcw + (size_t)j * 512 + part * 64);
+        const float4* cr = reinterpret_cast<const float4*>(cs + part * 64);
         float d = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) d = fmaf(cs[lane + 64 * i], fcw[(size_t)j * 512 + lane + 64 * i], d);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
-        if (lane == 0) {
+        for (int i = 0; i < 16; ++i) {
+            const float4 wv4 = wr[i], c4 = cr[i];
+            d = fmaf(c4.x, wv4.x, d); d = fmaf(c4.y, wv4.y, d); d = fmaf(c4.z, wv4.z, d); d = fmaf(c4.w, wv4.w, d);
+        }
+        d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+        if (part == 0) {
             d += fcb[j];
             lg[j] = d;
             logits[(size_t)b * C + j] = d;
