@@ -309,7 +309,6 @@ static __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __rest
     }
     if (threadIdx.x == 0) loss[0] = red[0] / (float)B;
 }
-
 // ------------------------------------------------------------------------------------------
 // head backward: fc + attention pooling (models.py:63-67)
 //   dctx = dlogits fc_w;  w = softmax_t(y a + b);  dw_t = <dctx, y_t>;  ds_t = w_t (dw_t - sum w dw)
@@ -334,28 +333,43 @@ static __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < 8; ++i) a8[i] = aw[lane + 64 * i];
     __syncthreads();
-    for (int t = wv; t < S; t += 4) {
-        float d = 0.0f, g = 0.0f;
+    float dc8[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float yv = yb[(size_t)t * 512 + lane + 64 * i];
-            d = fmaf(yv, a8[i], d);
-            g = fmaf(yv, dctx[lane + 64 * i], g);
+    for (int i = 0; i < 8; ++i) dc8[i] = dctx[lane + 64 * i];
+    // four time steps per wave and round, all 32 loads issued before the first reduction (cf. attention_pool_kernel)
+    for (int t0 = 4 * wv; t0 < S; t0 += 16) {
+        float v[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[k][i] = (t0 + k < S) ? yb[(size_t)(t0 + k) * 512 + lane + 64 * i] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float d = 0.0f, g = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                d = fmaf(v[k][i], a8[i], d);
+                g = fmaf(v[k][i], dc8[i], g);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { d += __shfl_xor(d, o); g += __shfl_xor(g, o); }
+            if (lane == 0 && t0 + k < S) { sc[t0 + k] = d + ab[0]; ds[t0 + k] = g; }   // ds holds dw_t for now
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { d += __shfl_xor(d, o); g += __shfl_xor(g, o); }
-        if (lane == 0) { sc[t] = d + ab[0]; ds[t] = g; }          // ds holds dw_t for now
     }
     __syncthreads();
+    // softmax weights once per time step (thread t)
+    __shared__ float ex[ATT_MAX_S];
     float mx = -INFINITY;
     for (int t = 0; t < S; ++t) mx = fmaxf(mx, sc[t]);
+    for (int t = tid; t < S; t += 256) ex[t] = expf(sc[t] - mx);
+    __syncthreads();
     float den = 0.0f;
-    for (int t = 0; t < S; ++t) den += expf(sc[t] - mx);
+    for (int t = 0; t < S; ++t) den += ex[t];
     float wdw = 0.0f;
-    for (int t = 0; t < S; ++t) wdw = fmaf(expf(sc[t] - mx) / den, ds[t], wdw);
+    for (int t = 0; t < S; ++t) wdw = fmaf(ex[t] / den, ds[t], wdw);
     __syncthreads();
     for (int t = tid; t < S; t += 256) {
-        const float w = expf(sc[t] - mx) / den;
+        const float w = ex[t] / den;
         const float dst = w * (ds[t] - wdw);
         sc[t] = w;                 // now the attention weight
         ds[t] = dst;               // now d score
