@@ -17,6 +17,7 @@
 //
 // HBM traffic per utterance (algorithmic): L*4 B read (L*2 for PCM16) + n_mels*t_pad*4 B written;
 // the un-normalised dB tile makes one extra round trip that stays in L2/MALL (24 KB per 3 s clip).
+#include <stdint.h>
 #include "sir_internal.h"
 
 namespace {
@@ -278,19 +279,25 @@ __global__ __launch_bounds__(256) void feat_normalise_kernel(
     if (L > max_len) L = max_len;
     const int T = (L > SIR_HOP) ? 1 + L / SIR_HOP : 0;
     const int tv = T < t_pad ? T : t_pad;
-    // merge chunk statistics (Chan et al.), every thread redundantly: nchunks <= ~10
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (int c = 0; c < nchunks; ++c) {
-        const float4 st = stats[(size_t)b * nchunks + c];
-        if (st.x > 0.0f) {
-            const double nc = st.x, delta = (double)st.y - mean, tot = n + nc;
-            mean += delta * nc / tot;
-            m2 += (double)st.z + delta * delta * n * nc / tot;
-            n = tot;
+    // merge chunk statistics (Chan et al.) ONCE per workgroup: the double-precision divisions of the merge, repeated by
+    // every thread, were most of this kernel (a dozen elements per thread of actual work)
+    __shared__ float s_mean, s_denom;
+    if (threadIdx.x == 0) {
+        double n = 0.0, mean = 0.0, m2 = 0.0;
+        for (int c = 0; c < nchunks; ++c) {
+            const float4 st = stats[(size_t)b * nchunks + c];
+            if (st.x > 0.0f) {
+                const double nc = st.x, delta = (double)st.y - mean, tot = n + nc;
+                mean += delta * nc / tot;
+                m2 += (double)st.z + delta * delta * n * nc / tot;
+                n = tot;
+            }
         }
+        s_mean = (float)mean;
+        s_denom = (n > 1.0 ? (float)sqrt(m2 / (n - 1.0)) : 0.0f) + NORM_EPS;
     }
-    const float meanf = (float)mean;
-    const float denom = (n > 1.0 ? (float)sqrt(m2 / (n - 1.0)) : 0.0f) + NORM_EPS;
+    __syncthreads();
+    const float meanf = s_mean, denom = s_denom;
     int tm0 = 0, tmw = 0, fm0 = 0, fmw = 0;
     if (time_mask) { tm0 = time_mask[2 * b]; tmw = time_mask[2 * b + 1]; }
     if (freq_mask) { fm0 = freq_mask[2 * b]; fmw = freq_mask[2 * b + 1]; }
@@ -298,6 +305,31 @@ __global__ __launch_bounds__(256) void feat_normalise_kernel(
     float* o = out + ((size_t)b * n_mels + row0) * t_pad;
     float* dbo = db_out ? db_out + ((size_t)b * n_mels + row0) * t_pad : nullptr;
     const int rows = (n_mels - row0) < NORM_ROWS ? (n_mels - row0) : NORM_ROWS;
+    if ((t_pad & 3) == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(db_out)) & 15) == 0) {
+        // four frames per thread and iteration (rows are 16-byte aligned)
+        const int q4 = t_pad >> 2;
+        for (int i4 = threadIdx.x; i4 < rows * q4; i4 += 256) {
+            const int r = i4 / q4, t0 = 4 * (i4 - r * q4), mel = row0 + r;
+            const bool fmasked = mel >= fm0 && mel < fm0 + fmw;
+            float4* op = reinterpret_cast<float4*>(o + (size_t)r * t_pad + t0);
+            float4 dbv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t0 < tv) dbv = *op;
+            float dbs[4] = {dbv.x, dbv.y, dbv.z, dbv.w}, vs[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = t0 + e;
+                float v = 0.0f;
+                if (t < tv) {
+                    v = (dbs[e] - meanf) / denom;
+                    if ((t >= tm0 && t < tm0 + tmw) || fmasked) v = 0.0f;
+                } else dbs[e] = 0.0f;
+                vs[e] = v;
+            }
+            *op = make_float4(vs[0], vs[1], vs[2], vs[3]);
+            if (dbo) *reinterpret_cast<float4*>(dbo + (size_t)r * t_pad + t0) = make_float4(dbs[0], dbs[1], dbs[2], dbs[3]);
+        }
+        return;
+    }
     for (int idx = threadIdx.x; idx < rows * t_pad; idx += 256) {
         const int r = idx / t_pad, t = idx - r * t_pad;
         float v = 0.0f, db = 0.0f;
