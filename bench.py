@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: batched audio -> intent inference on MI355X.
+"""Benchmark of the hot path: batched audio -> intent inference (and the training step) on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -8,7 +8,16 @@ are already resident in HBM: fused HIP feature extraction (framed rFFT -> mel ->
 pad to 200 frames) followed by the HIP CNN/BiGRU/attention forward and argmax -- BASELINE.json
 configs[1].  Utterances are independent, so N > 1 shards them (one process per GPU, 256 per GPU
 per step, weak scaling) with no collective on the data path; torch.distributed (RCCL) is used only
-for the barrier and the max-over-ranks of the elapsed time.
+for the barrier and the max-over-ranks of the elapsed time.  The training legs (`train`, `train_aug`
+in the same JSON line: configs[2] / [3] / [4]) end every step in the RCCL all-reduce of the 13 MB gradient.
+
+Launching: with --gpus N > 1 and no WORLD_SIZE in the environment this process is only a LAUNCHER: it
+starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child BEFORE touching the
+GPU (it never does), relays rank 0's JSON line and exits with the child's code.  Started by an external
+launcher (WORLD_SIZE set) it is one rank; WORLD_SIZE != --gpus is an error, not a silent downgrade.
+
+Every timed figure is the MEDIAN of `--repeats` (5) timed regions of exactly K steps, each bracketed by
+barrier + synchronize on both sides and max-reduced over ranks; min / max are reported.
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
   roofline     -- dominant kernel, achieved vs peak, timed live with HIP events on its stream
@@ -19,6 +28,9 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -35,31 +47,102 @@ NUM_CLASSES = 31
 N_POOL = 8                       # distinct batches staged in HBM (8 x 49 MB > the 256 MB MALL)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: bf16 MFMA, dense (no sparsity)
-# kernels that compute their fp32 contraction as 6 bf16 MFMA products per fp32 product ("bf16x6",
+# every contraction of the path computes its fp32 products as 6 bf16 MFMA products ("bf16x6",
 # csrc/bf16x6_kernels.h): the matrix pipe executes 6x the algorithmic FLOPs, so the peak for
 # ALGORITHMIC fp32 FLOP/s on that path is 2500/6 TFLOP/s
-BF16X6_KERNELS = set()
-if int(os.environ.get("SIR_CONV_BF16X6", "1")):
-    BF16X6_KERNELS |= {"conv2_mfma_bn_relu_pool", "conv3_mfma_bn_relu_pool"}
-if int(os.environ.get("SIR_GEMM_VARIANT", "2")) == 2:
-    BF16X6_KERNELS |= {"gemm_ih_l0", "gemm_ih_l1"}
+PEAK_BF16X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
 
 # algorithmic work per utterance at T = 200 frames
+_CONV2 = 2 * 64 * 288 * 32 * 100
+_CONV3 = 2 * 128 * 576 * 16 * 50
+_IH0 = 2 * 25 * 1024 * 1536
+_IH1 = 2 * 25 * 512 * 1536
+_REC = 2 * 25 * 2 * 768 * 256
 FLOPS_PER_UTT = {
     "conv1_bn_relu_pool": 2 * 32 * 9 * 64 * 200,
-    "conv2_mfma_bn_relu_pool": 2 * 64 * 288 * 32 * 100,
-    "conv3_mfma_bn_relu_pool": 2 * 128 * 576 * 16 * 50,
-    "gemm_ih_l0": 2 * 25 * 1024 * 1536,
-    "gemm_ih_l1": 2 * 25 * 512 * 1536,
-    "gru_recurrence_l0": 2 * 25 * 2 * 768 * 256,
-    "gru_recurrence_l1": 2 * 25 * 2 * 768 * 256,
+    "conv2_mfma_bn_relu_pool": _CONV2, "conv3_mfma_bn_relu_pool": _CONV3,
+    "gemm_ih_l0": _IH0, "gemm_ih_l1": _IH1, "gru_recurrence_l0": _REC, "gru_recurrence_l1": _REC,
+    # training step: forward twins, data gradients (same contraction sizes) and weight gradients
+    "train_conv1_fwd": 2 * 32 * 9 * 64 * 200, "train_conv2_fwd": _CONV2, "train_conv3_fwd": _CONV3,
+    "train_gemm_ih_l0": _IH0, "train_gemm_ih_l1": _IH1, "train_gru_l0": _REC, "train_gru_l1": _REC,
+    "bwd_gru_l1": _REC, "bwd_gru_l0": _REC,
+    "bwd_gru_dw_l1": 2 * 25 * 1536 * (512 + 256), "bwd_gru_dw_l0": 2 * 25 * 1536 * (1024 + 256),
+    "bwd_gru_dx_l1": _IH1, "bwd_gru_dx_l0": _IH0,
+    "bwd_conv3_wgrad": _CONV3, "bwd_conv3_dgrad": _CONV3, "bwd_conv2_wgrad": _CONV2, "bwd_conv2_dgrad": _CONV2,
 }
+BF16X6_KERNELS = {k for k in FLOPS_PER_UTT if "conv1" not in k}
+FWD_FLOPS_PER_UTT = 400646144
+TRAIN_FLOPS_PER_UTT = 3 * FWD_FLOPS_PER_UTT                  # fwd + dgrad + wgrad convention: 1 201 938 432
 FEATURE_BYTES_PER_UTT = CLIP_LEN * 4 + 64 * T_PAD * 4       # 243 200 B (fp32 waveform in, features out)
+# GRU recurrence, algorithmic HBM bytes per launch at B = 256 (gate pre-activations in, y out, + the bf16x3 planes of y
+# that layer 0 writes for the next projection): VERDICT r1 item 6
+GRU_ALGO_BYTES = {"gru_recurrence_l0": BATCH * 25 * (1536 * 4 + 512 * 4 + 512 * 6), "gru_recurrence_l1": BATCH * 25 * (1536 * 4 + 512 * 4)}
 
 
 def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+# ---- launcher (parent process; never touches the GPU) ---------------------------------------------------------------
+def launcher_command(n_gpus, port, bench_args, python=None, script=None):
+    """argv of the child that runs N ranks of this script: one process per GPU under torch.distributed.run."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(bench_args)
+
+
+def launcher_env(base):
+    """Environment of the child: the caller's, plus what multi-process GPU work needs on this pool."""
+    env = dict(base)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC (RCCL across processes)
+    env["SIR_BENCH_LAUNCHED_BY"] = "bench.py"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)                                      # torch.distributed.run sets them per rank
+    return env
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def pick_json_line(lines):
+    """The last line that is a JSON object carrying "metric" (rank 0's result)."""
+    for line in reversed(lines):
+        line = line.strip()
+        if line.startswith("{"):
+            try:
+                d = json.loads(line)
+            except ValueError:
+                continue
+            if isinstance(d, dict) and "metric" in d:
+                return line
+    return None
+
+
+def launch_ranks(n_gpus, bench_args):
+    """Parent of an N-rank run.  No HIP call is made here: device_count() does not initialise the runtime."""
+    share = os.environ.get("SIR_BENCH_SHARE_GPU", "0") == "1"
+    ndev = torch.cuda.device_count()
+    if not share and ndev < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} but only {ndev} GPU(s) are visible (SIR_BENCH_SHARE_GPU=1 rehearses N ranks "
+              "on one GPU over gloo)", file=sys.stderr)
+        return 2
+    cmd = launcher_command(n_gpus, free_port(), bench_args)
+    log("launching " + " ".join(cmd))
+    proc = subprocess.Popen(cmd, env=launcher_env(os.environ), stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout]
+    rc = proc.wait()
+    result = pick_json_line(lines)
+    for ln in lines:
+        if ln.strip() != (result or "").strip():
+            sys.stderr.write(ln)
+    if result is None:
+        print(f"bench.py: the {n_gpus}-rank run printed no result line (exit code {rc})", file=sys.stderr)
+        return rc or 1
+    print(result, flush=True)
+    return rc
 
 
 def host_cpu_share(cap=16):
@@ -88,17 +171,19 @@ def host_cpu_share(cap=16):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc pass (profiles/*/pmc_traffic.json,
-    written by devtools/gpu_pmc.sh + tools in profiles/), or None when no measurement is on file."""
+    """(HBM bytes per launch of `kernel`, source) from the newest COMMITTED rocprofv3 --pmc pass
+    (profiles/*/pmc_traffic.json, written by devtools/gpu_pmc.sh + profiles/pmc_to_traffic.py) -- not measured in
+    this run, and labelled so -- or (None, None) when no measurement is on file."""
     try:
         import glob
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")))
         if not files:
-            return None
+            return None, None
         with open(files[-1]) as f:
-            return (json.load(f).get(kernel) or {}).get("hbm_bytes_per_launch")
+            v = (json.load(f).get(kernel) or {}).get("hbm_bytes_per_launch")
+        return v, f"{os.path.relpath(files[-1], ROOT)} (committed rocprofv3 --pmc pass, not measured in this run)"
     except Exception:
-        return None
+        return None, None
 
 
 def device_clips(n, length, seed, device):
@@ -191,26 +276,47 @@ def cpu_train_baseline(cores, target_seconds=8.0):
             "batch8_value": round(out[8][0], 2), "batch256_value": round(out[256][0], 2)}
 
 
+def mfma_roofline(kernel, avg_ms, launches, batch=BATCH):
+    """roofline block of one matrix-core kernel from its average launch duration."""
+    flops = FLOPS_PER_UTT[kernel] * batch
+    achieved = flops / (avg_ms * 1e-3) / 1e12
+    x6 = kernel in BF16X6_KERNELS
+    peak = PEAK_BF16X6_TFLOPS if x6 else PEAK_F32_MFMA_TFLOPS
+    traffic, source = pmc_traffic(kernel)
+    return {"kernel": kernel, "bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": source,
+            "avg_launch_ms": round(avg_ms, 5), "launches": launches, "flops_per_launch": flops,
+            "mfma_path": ("bf16x6: fp32 product = 6 bf16 MFMA products, f32 accumulate; peak = 2500/6 "
+                          "algorithmic TFLOP/s; executed bf16 MFMA rate = 6 x achieved") if x6 else "v_mfma_f32_32x32x2_f32",
+            "fp32_mfma_peak": PEAK_F32_MFMA_TFLOPS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train", action="store_true", help="skip the training-step leg")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step legs")
+    ap.add_argument("--augment", dest="augment", action="store_true", default=True,
+                    help="also time the training step with fused time-shift + noise + SpecAugment masks (default on)")
+    ap.add_argument("--no-augment", dest="augment", action="store_false")
     ap.add_argument("--train-steps", type=int, default=20)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("SIR_BENCH_STREAMS", "2")),
                     help="HIP streams the inference batches alternate over (each with its own buffers/workspace)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))       # parent: launcher only, before any GPU call
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        args.gpus = world
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to run a different job than the one asked for",
+              file=sys.stderr)
+        sys.exit(2)
     # SIR_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box): every rank uses cuda:0 and the gloo backend, to exercise
     # the multi-rank code path; real runs use one GPU per rank and RCCL ("nccl")
     share_gpu = os.environ.get("SIR_BENCH_SHARE_GPU", "0") == "1"
@@ -226,7 +332,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from sir_amd import _native, synth
+    from sir_amd import _native, ops, synth
     from sir_amd.featurizer import get_featurizer
     from sir_amd.models.models import CNNAudioGRU
     if not os.path.exists(_native.LIB_PATH):
@@ -235,6 +341,20 @@ def main():
         if dist is not None:
             dist.barrier()
     lib = _native.lib()
+
+    # what the process group really is (so that "RCCL saw N ranks" is checkable from the JSON line)
+    my_dev = f"rank{rank}:cuda:{local_rank}:{torch.cuda.get_device_name(local_rank)}"
+    try:
+        my_dev += ":" + str(torch.cuda.get_device_properties(local_rank).uuid)
+    except Exception:
+        pass
+    if dist is not None:
+        devices = [None] * world
+        dist.all_gather_object(devices, my_dev)
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices": devices,
+                     "launcher": os.environ.get("SIR_BENCH_LAUNCHED_BY", "external")}
+    else:
+        dist_info = {"world_size": 1, "backend": None, "devices": [my_dev], "launcher": None}
 
     sd = synth.synth_state_dict(NUM_CLASSES, seed=0)
     model = CNNAudioGRU(NUM_CLASSES)
@@ -266,6 +386,32 @@ def main():
         _native.check(lib.sir_profile_collect(fz.handle, ms, cnt, nk), "sir_profile_collect")
         return {names[i]: (ms[i] / cnt[i] if cnt[i] else 0.0) for i in range(nk)}, {names[i]: cnt[i] for i in range(nk)}
 
+    def timed_regions(fn, steps, repeats):
+        """`repeats` regions of exactly `steps` steps: barrier + synchronize on both sides, max over ranks."""
+        out = []
+        for r in range(repeats):
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                fn(r * steps + i)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                tm = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                el = float(tm.item())
+            out.append(el)
+        return out
+
+    def region_stats(times, steps):
+        ms = sorted(t / steps * 1e3 for t in times)
+        return {"repeats": len(ms), "steps_per_region": steps, "median_ms_per_step": round(statistics.median(ms), 4),
+                "min_ms_per_step": round(ms[0], 4), "max_ms_per_step": round(ms[-1], 4)}
+
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -278,25 +424,17 @@ def main():
         step(i)
         torch.cuda.synchronize()          # one batch at a time: per-kernel times without cross-stream overlap
     kernel_ms, _ = collect()
-    dominant = max(kernel_ms, key=kernel_ms.get)
+    infer_names = names[:names.index("train_weight_prep")]
+    dominant = max(infer_names, key=lambda k: kernel_ms[k])
     lib.sir_profile_enable(fz.handle, 2, names.index(dominant))
 
-    # timed region: exactly K steps, barrier + synchronize on both sides; the dominant kernel is
-    # bracketed by a HIP event pair on its own stream (2 events per step)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    # timed regions: exactly K steps each; the dominant kernel is bracketed by a HIP event pair on its own stream
+    times = timed_regions(step, args.steps, args.repeats)
+    elapsed = statistics.median(times)
     if rank == 0:
-        log(f"timed {args.steps} steps in {elapsed:.3f} s")
+        log(f"timed {args.repeats} x {args.steps} steps: median {elapsed:.4f} s")
     dom_ms, dom_cnt = collect()
-    # reference leg: the same K steps on ONE stream (no batch pipelining), dominant kernel timed in isolation
+    # reference leg: the same regions on ONE stream (no batch pipelining), dominant kernel timed in isolation
     single = None
     if ns > 1:
         pipe1 = BatchPipeline(model, n_streams=1)
@@ -308,111 +446,107 @@ def main():
             step1(i)
         torch.cuda.synchronize()
         collect()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            step1(i)
-        torch.cuda.synchronize()
-        el1 = time.perf_counter() - t1
-        iso_ms, _ = collect()
+        t1 = timed_regions(step1, args.steps, args.repeats)
+        el1 = statistics.median(t1)
+        iso_ms, iso_cnt = collect()
         single = {"value": round(BATCH * world * args.steps / el1, 1), "ms_per_step": round(el1 / args.steps * 1e3, 4),
-                  "dominant_avg_launch_ms": round(iso_ms[dominant], 5)}
+                  "timed_regions": region_stats(t1, args.steps),
+                  "dominant_avg_launch_ms": round(iso_ms[dominant], 5), "dominant_launches": iso_cnt[dominant]}
     lib.sir_profile_enable(fz.handle, 0, -1)
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
 
-    # second leg (reported inside the same JSON line): the training step of BASELINE configs[2]/[3]
+    # further legs (reported inside the same JSON line): the training step of BASELINE configs[2]/[3]/[4]
     # -- fused HIP features + forward/backward + Adam at per-GPU batch 256; with N > 1 each step
-    # ends in one RCCL all-reduce (mean) of the flat 13 MB gradient buffer.
+    # ends in the RCCL all-reduce (mean) of the flat 13 MB gradient buffer (two buckets, overlapped).
     gpu_pred32 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # predictions of the sample the CPU baseline runs, taken before the training leg moves the weights
         _, gpu_pred32 = model.predict(fz(synth.synth_clips(32, CLIP_LEN, seed=1234).to(dev)))
         gpu_pred32 = gpu_pred32.cpu()
-    train_info = None
+    train_info = train_aug_info = None
     if not args.no_train:
         from sir_amd import train_ops
         from sir_amd.optim import FusedAdam
+        from sir_amd.scripts import augment as aug
+        import random
         model.train()
         opt = FusedAdam(model.parameters(), lr=5e-5, weight_decay=1e-4)
         labels = torch.randint(0, NUM_CLASSES, (BATCH,), device=dev)
+        host_lengths = [CLIP_LEN] * BATCH
+        rng = random.Random(4321 + rank)
 
-        # SIR_BENCH_PREFETCH=1 extracts the features of batch i + 1 on a side stream beside the backward of step i
-        # (FeaturePrefetcher).  Measured A/B on one box: 3.19 vs 3.17 ms per step -- the recurrences leave nothing a
-        # competing kernel can use -- so the default keeps everything on one stream.
-        prefetch = os.environ.get("SIR_BENCH_PREFETCH", "0") != "0"
-        if prefetch:
-            from sir_amd.pipeline import FeaturePrefetcher
-            pre = FeaturePrefetcher(t_pad=T_PAD)
-            pre.submit(pool[0], lengths)
-
-        def tstep(i):
-            x = pre.get() if prefetch else fz(pool[i % N_POOL], lengths, t_pad=T_PAD, out=feats[0])
+        def tstep(i, augment=False):
+            kw = {}
+            if augment:
+                # BASELINE configs[4]: shift U(-0.1, 0.1) * L and sigma U(1e-3, 1e-2) with the reference's gating
+                # (scripts/augment.py:98-135), SpecAugment bands (dataset.py:160-176), all applied inside the feature kernels
+                shift, sigma = aug.draw_batch_params(host_lengths, 0.7, rng)
+                tm, fm = aug.draw_spec_masks([1 + n // 512 for n in host_lengths], 0.5, rng=rng)
+                kw = dict(shift=shift, noise_sigma=sigma, noise_seed=(rank << 32) ^ i, time_mask=tm, freq_mask=fm)
+            x = fz(pool[i % N_POOL], lengths, t_pad=T_PAD, out=feats[0], **kw)
             opt.zero_grad(set_to_none=True)
             loss = train_ops.fused_cross_entropy(model(x), labels)
-            if prefetch:                      # queued behind the forward: runs beside the backward GRU recurrence
-                pre.submit(pool[(i + 1) % N_POOL], lengths)
             loss.backward()
             opt.step()
-            if prefetch:
-                pre.release()
 
-        for i in range(5):
-            tstep(i)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(args.train_steps):
-            tstep(i)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        t_el = time.perf_counter() - t1
-        if dist is not None:
-            tm = torch.tensor([t_el], dtype=torch.float64, device=dev)
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            t_el = float(tm.item())
-        train_info = {"value": round(BATCH * world * args.train_steps / t_el, 1), "unit": "utterances/s",
-                      "ms_per_step": round(t_el / args.train_steps * 1e3, 4), "steps": args.train_steps,
-                      "workload": "waveform batch 256/GPU -> HIP features -> forward/backward (dropout 0.5, batch-stat BN) "
-                                  "-> Adam(lr 5e-5, wd 1e-4)" + (", RCCL all-reduce of 13 MB grads" if world > 1 else ""),
-                      "model_flops_per_utt_fwd_bwd": 3 * sum(FLOPS_PER_UTT.values()),
-                      "feature_prefetch": prefetch}
+        def train_leg(augment):
+            fn = (lambda i: tstep(i, True)) if augment else tstep
+            for i in range(5):
+                fn(i)
+            torch.cuda.synchronize()
+            lib.sir_profile_enable(fz.handle, 1, -1)              # untimed: per-kernel times of three steps
+            for i in range(3):
+                fn(i)
+            torch.cuda.synchronize()
+            tk_ms, _ = collect()
+            tdom = max((k for k in tk_ms if k in FLOPS_PER_UTT and k in BF16X6_KERNELS), key=lambda k: tk_ms[k])
+            lib.sir_profile_enable(fz.handle, 2, names.index(tdom))
+            tt = timed_regions(fn, args.train_steps, args.repeats)
+            td_ms, td_cnt = collect()
+            lib.sir_profile_enable(fz.handle, 0, -1)
+            t_el = statistics.median(tt)
+            ms = t_el / args.train_steps * 1e3
+            step_tf = TRAIN_FLOPS_PER_UTT * BATCH / (ms * 1e-3) / 1e12
+            info = {"value": round(BATCH * world * args.train_steps / t_el, 1), "unit": "utterances/s",
+                    "ms_per_step": round(ms, 4), "steps": args.train_steps, "timed_regions": region_stats(tt, args.train_steps),
+                    "workload": "waveform batch 256/GPU -> HIP features" +
+                                (" with fused time-shift + noise + SpecAugment masks" if augment else "") +
+                                " -> forward/backward (dropout 0.5, batch-stat BN) -> Adam(lr 5e-5, wd 1e-4)" +
+                                (", RCCL all-reduce of 13 MB grads in two overlapped buckets" if world > 1 else ""),
+                    "model_flops_per_utt_fwd_bwd": TRAIN_FLOPS_PER_UTT,
+                    "roofline": dict(mfma_roofline(tdom, td_ms[tdom], td_cnt[tdom]),
+                                     whole_step={"flops_per_step": TRAIN_FLOPS_PER_UTT * BATCH, "achieved": round(step_tf, 2),
+                                                 "peak": round(PEAK_BF16X6_TFLOPS, 1), "unit": "TFLOP/s",
+                                                 "frac": round(step_tf / PEAK_BF16X6_TFLOPS, 4),
+                                                 "note": "1.2019 GFLOP/utt (fwd + dgrad + wgrad convention) x 256 / per-GPU step time"}),
+                    "kernels_avg_ms": {k: round(v, 5) for k, v in tk_ms.items() if v > 0.0}}
+            if rank == 0:
+                log(f"train leg (augment={augment}): {info['value']} utt/s")
+            return info
+
+        train_info = train_leg(False)
+        if args.augment:
+            train_aug_info = train_leg(True)
         model.eval()
-        if rank == 0:
-            log(f"train leg: {train_info['value']} utt/s")
+    ops.check_status()                                          # a timed-out GRU recurrence would invalidate every figure
 
     if rank == 0:
         total_utts = BATCH * world * args.steps
         value = total_utts / elapsed
         d_ms = dom_ms[dominant]
         if dominant in FLOPS_PER_UTT:
-            achieved = FLOPS_PER_UTT[dominant] * BATCH / (d_ms * 1e-3) / 1e12
-            x6 = dominant in BF16X6_KERNELS
-            peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if x6 else PEAK_F32_MFMA_TFLOPS
-            roofline = {"kernel": dominant, "bound": "mfma", "achieved": round(achieved, 3),
-                        "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                        "traffic": pmc_traffic(dominant), "avg_launch_ms": round(d_ms, 5), "launches": dom_cnt[dominant],
-                        "flops_per_launch": FLOPS_PER_UTT[dominant] * BATCH,
-                        "mfma_path": ("bf16x6: fp32 product = 6 bf16 MFMA products, f32 accumulate; peak = 2500/6 "
-                                      "algorithmic TFLOP/s; executed bf16 MFMA rate = 6 x achieved") if x6
-                        else "v_mfma_f32_32x32x2_f32",
-                        "fp32_mfma_peak": PEAK_F32_MFMA_TFLOPS}
+            roofline = mfma_roofline(dominant, d_ms, dom_cnt[dominant])
             if single is not None:
                 # with several streams the kernel's launches in the pipelined region share the CUs with the other stream's
                 # kernels (its "duration" then includes co-scheduling); the roofline of the KERNEL is taken from the
                 # single-stream timed leg of this same run (K steps, HIP events on the launch stream), and the pipelined
                 # figures are kept beside it
-                iso = FLOPS_PER_UTT[dominant] * BATCH / (single["dominant_avg_launch_ms"] * 1e-3) / 1e12
-                roofline["pipelined"] = {"streams": ns, "avg_launch_ms": roofline["avg_launch_ms"], "achieved": roofline["achieved"],
-                                         "frac": roofline["frac"],
-                                         "note": "same kernel inside the multi-stream timed region: it shares the GPU with the other "
-                                                 "stream's kernels, so its launch duration includes co-scheduling"}
-                roofline.update({"achieved": round(iso, 3), "frac": round(iso / peak, 4),
-                                 "avg_launch_ms": single["dominant_avg_launch_ms"], "launches": args.steps,
-                                 "measured_in": "single-stream timed leg of this run (same K steps, one HIP stream)"})
+                iso = mfma_roofline(dominant, single["dominant_avg_launch_ms"], single["dominant_launches"])
+                iso["pipelined"] = {"streams": ns, "avg_launch_ms": roofline["avg_launch_ms"], "achieved": roofline["achieved"],
+                                    "frac": roofline["frac"],
+                                    "note": "same kernel inside the multi-stream timed region: it shares the GPU with the other "
+                                            "stream's kernels, so its launch duration includes co-scheduling"}
+                iso["measured_in"] = "single-stream timed leg of this run (same K steps, one HIP stream)"
+                roofline = iso
         else:
             achieved = FEATURE_BYTES_PER_UTT * BATCH / (d_ms * 1e-3) / 1e9
             roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS,
@@ -420,11 +554,18 @@ def main():
                         "avg_launch_ms": round(d_ms, 5), "launches": dom_cnt[dominant],
                         "bytes_per_launch": FEATURE_BYTES_PER_UTT * BATCH}
         feat_ms = kernel_ms.get("feat_frames", 0.0) + kernel_ms.get("feat_normalise", 0.0)
+        gru = {}
+        for k, algo in GRU_ALGO_BYTES.items():
+            tr, src = pmc_traffic(k)
+            gru[k] = {"avg_ms": round(kernel_ms.get(k, 0.0), 5), "algorithmic_bytes_per_launch": algo, "traffic": tr,
+                      "traffic_source": src, "traffic_over_algorithmic": round(tr / algo, 2) if tr else None,
+                      "achieved_TFLOPs": round(FLOPS_PER_UTT[k] * BATCH / (kernel_ms[k] * 1e-3) / 1e12, 2) if kernel_ms.get(k) else None}
         out = {
             "metric": "utterances/sec (16 kHz, 3 s clips), inference: HIP STFT+mel+CNN/BiGRU forward + argmax",
             "value": round(value, 1), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "timed_regions": region_stats(times, args.steps),
             "config": {"workload": "1xMI355X inference (BASELINE configs[1]): batch=256 synthetic 16 kHz / 3 s clips "
                                    "resident in HBM -> 64-mel log-mel [64,200] -> CNNAudioGRU(31) forward -> argmax",
                        "batch_per_gpu": BATCH, "clip_samples": CLIP_LEN, "n_mels": 64, "frames": T_PAD,
@@ -432,22 +573,34 @@ def main():
                        "streams_per_gpu": ns,
                        "arithmetic": "fp32 accuracy end to end: contractions as bf16x6 (three-way bf16 split of both operands, six "
                                      "v_mfma_f32_32x32x16_bf16 products, f32 accumulation), everything else fp32 VALU"},
+            "dist": dist_info,
             "roofline": roofline,
-            "kernels_avg_ms": {k: round(v, 5) for k, v in kernel_ms.items()},
+            "kernels_avg_ms": {k: round(kernel_ms[k], 5) for k in infer_names},
             "features_stage": {"bound": "hbm", "avg_ms": round(feat_ms, 5),
                                "achieved_GBs": round(FEATURE_BYTES_PER_UTT * BATCH / (feat_ms * 1e-3) / 1e9, 1) if feat_ms else None,
-                               "peak_GBs": PEAK_HBM_GBS},
+                               "peak_GBs": PEAK_HBM_GBS, "frac": round(FEATURE_BYTES_PER_UTT * BATCH / (feat_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if feat_ms else None,
+                               "bytes_per_launch": FEATURE_BYTES_PER_UTT * BATCH},
+            "gru_recurrence": gru,
         }
         if single is not None:
             out["single_stream"] = single
         if train_info is not None:
             out["train"] = train_info
+        if train_aug_info is not None:
+            out["train_aug"] = train_aug_info
         if world == 1 and not args.no_cpu_baseline:
             base, cpu_pred = cpu_baseline()
             out["cpu_baseline"] = base
             out["speedup_vs_cpu_all_cores"] = round(value / base["value"], 1)
             # parity flag on the very sample the CPU baseline ran: predicted indices identical
-            out["parity"] = {"argmax_identical_on_cpu_sample": bool(torch.equal(gpu_pred32, cpu_pred))}
+            out["parity"] = {"argmax_identical_on_cpu_sample": bool(torch.equal(gpu_pred32, cpu_pred)),
+                             "tolerances": {"features": "|a-b| <= 1e-4*max(1,|b|) on dB and normalised features (north_star 1e-4 rel); "
+                                                        "pure-tone clips (> 100 dB dynamic range): 2x the float32 oracle's own error vs "
+                                                        "float64, floor 1e-3 dB (tests/test_features_gpu.py) -- looser than 1e-4",
+                                            "logits": "<= 2e-5 abs vs the reference's own outputs", "argmax": "identical",
+                                            "gradients": "max|a-b| <= 2e-3*rms(b) per tensor (oracle at the device's ReLU/pool decisions)"},
+                             "feature_oracle": "parity unpinned by the reference (torchaudio absent, no vectors); cross-checked "
+                                               "against transformers.audio_utils.spectrogram (tests/test_oracle_golden.py)"}
             if train_info is not None:
                 tb = cpu_train_baseline(base["cores"])
                 out["train"]["cpu_baseline"] = tb

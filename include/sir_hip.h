@@ -29,6 +29,7 @@ extern "C" {
 #define SIR_ENOMEM (-2)   /* workspace too small / hipMalloc failed */
 #define SIR_EHIP (-3)     /* HIP runtime error */
 #define SIR_EUNSUPPORTED (-4)
+#define SIR_ETIMEOUT (-5) /* a GRU recurrence kernel gave up waiting for a peer workgroup: results invalid */
 
 #define SIR_WAVE_F32 0
 #define SIR_WAVE_I16 1    /* PCM16; dequantised as s / 32768 (torchaudio.load convention) */
@@ -159,6 +160,14 @@ int sir_model_set_weights_version(sir_handle* h, uint64_t version);
 int sir_model_infer(sir_handle* h, const sir_model_weights* w, const float* feats, int batch,
                     int t_frames, float* logits, int64_t* argmax, void* workspace,
                     size_t workspace_bytes, void* stream);
+/* The GRU recurrence kernels (forward and backward) exchange hidden-state slices between the workgroups of a
+ * cluster through tagged granules in global memory and rely on the cluster being co-resident.  A workgroup that
+ * spins past its limit (a partitioned / oversubscribed GPU, a stalled peer) sets a device status word owned by the
+ * handle and carries on with invalid values.  sir_check_status waits for `stream`, returns SIR_ETIMEOUT if any
+ * recurrence launched on this handle since the last check timed out (and clears the word), SIR_OK otherwise.
+ * Call it wherever the host synchronises anyway -- once per batch of predictions (scripts/evaluate.py:85-86's
+ * .cpu()) or per epoch (scripts/train.py:116's loss.item()); sir_profile_collect performs the same check. */
+int sir_check_status(sir_handle* h, void* stream);
 
 /* ---- training step ----------------------------------------------------------------------------
  * Replaces the body of train_epoch (scripts/train.py:90-107): model(mel) in train() mode,

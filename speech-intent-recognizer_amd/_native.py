@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsir_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 SIR_OK = 0
+SIR_ETIMEOUT = -5
 WAVE_F32, WAVE_I16 = 0, 1
 BWD_ALL, BWD_HEAD_GRU, BWD_CNN = 0, 1, 2
 
@@ -64,6 +65,7 @@ SIGNATURES = {
     "sir_model_set_weights_version": (C.c_int, [C.c_void_p, C.c_uint64]),
     "sir_model_infer": (C.c_int, [C.c_void_p, C.POINTER(ModelWeights), C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sir_check_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sir_model_train_fwd": (C.c_int, [C.c_void_p, C.POINTER(ModelWeights), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                       C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p,
                                       C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -48,6 +48,7 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     h->weights_version = 0; h->prep_next = 0;
     for (auto& e : h->prep) { e.ws = nullptr; e.version = 0; e.key = -1; }
     h->tw512 = nullptr; h->tw1024 = nullptr; h->window = nullptr; h->melw = nullptr; h->mel_start = nullptr;
+    h->status = nullptr;
     h->cfg = *cfg;
     h->cfg.window = nullptr;
     h->cfg.mel_fb = nullptr;
@@ -99,6 +100,7 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     if (rc == SIR_OK) rc = upload(&h->window, window);
     if (rc == SIR_OK) rc = upload(&h->melw, melw);
     if (rc == SIR_OK) rc = upload(&h->mel_start, start);
+    if (rc == SIR_OK) rc = upload(&h->status, std::vector<unsigned int>(64, 0u));
     if (rc != SIR_OK) { sir_destroy(h); return rc; }
     *out = h;
     return SIR_OK;
@@ -107,7 +109,7 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
 extern "C" int sir_destroy(sir_handle* h) {
     if (!h) return SIR_OK;
     (void)hipFree(h->tw512); (void)hipFree(h->tw1024); (void)hipFree(h->window);
-    (void)hipFree(h->melw); (void)hipFree(h->mel_start);
+    (void)hipFree(h->melw); (void)hipFree(h->mel_start); (void)hipFree(h->status);
     for (auto& t : h->resample_tables) { (void)hipFree(t.taps); (void)hipFree(t.first); }
     for (auto& r : h->prof_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : h->prof_free) (void)hipEventDestroy(e);
@@ -133,7 +135,11 @@ extern "C" int sir_model_set_weights_version(sir_handle* h, uint64_t version) {
 static const char* const kKernelNames[SIR_K_COUNT] = {
     "feat_frames", "feat_normalise", "weight_prep", "conv1_bn_relu_pool", "conv2_mfma_bn_relu_pool",
     "conv3_mfma_bn_relu_pool", "gemm_ih_l0", "gru_recurrence_l0", "gemm_ih_l1", "gru_recurrence_l1",
-    "attention_pool_fc_argmax", "unused"};
+    "attention_pool_fc_argmax", "unused",
+    "train_weight_prep", "train_conv1_fwd", "train_conv2_fwd", "train_bn2_relu_pool", "train_conv3_fwd", "train_bn3_relu_pool",
+    "train_gemm_ih_l0", "train_gru_l0", "train_dropout", "train_gemm_ih_l1", "train_gru_l1", "train_attention_fc", "ce_loss",
+    "bwd_head", "bwd_gru_l1", "bwd_gru_dw_l1", "bwd_gru_dx_l1", "bwd_gru_l0", "bwd_gru_dw_l0", "bwd_gru_dx_l0",
+    "bwd_bn3", "bwd_conv3_wgrad", "bwd_conv3_dgrad", "bwd_bn2", "bwd_conv2_wgrad", "bwd_conv2_dgrad", "bwd_conv1", "adam"};
 
 extern "C" int sir_profile_kernel_count(void) { return SIR_K_COUNT; }
 extern "C" const char* sir_profile_kernel_name(int id) { return (id >= 0 && id < SIR_K_COUNT) ? kKernelNames[id] : ""; }
@@ -143,6 +149,24 @@ extern "C" int sir_profile_enable(sir_handle* h, int mode, int kernel_id) {
     h->prof_mode = mode;
     h->prof_only = kernel_id;
     return SIR_OK;
+}
+
+// Reads and clears the device status word behind everything queued on `stream` (host-synchronous on that stream).
+static int check_status_impl(sir_handle* h, hipStream_t st, const char* who) {
+    unsigned int v = 0;
+    SIR_HIP_TRY(hipMemcpyAsync(&v, h->status, sizeof(v), hipMemcpyDeviceToHost, st));
+    SIR_HIP_TRY(hipStreamSynchronize(st));
+    if (v == 0) return SIR_OK;
+    SIR_HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(v), st));
+    SIR_HIP_TRY(hipStreamSynchronize(st));
+    sir_set_error("%s: a GRU recurrence kernel timed out waiting for a peer workgroup of its cluster (status %u): the "
+                  "logits / gradients produced since the last check are invalid", who, v);
+    return SIR_ETIMEOUT;
+}
+
+extern "C" int sir_check_status(sir_handle* h, void* stream) {
+    if (!h) { sir_set_error("sir_check_status: NULL handle"); return SIR_EINVAL; }
+    return check_status_impl(h, (hipStream_t)stream, "sir_check_status");
 }
 
 extern "C" int sir_profile_collect(sir_handle* h, double* total_ms, int64_t* launches, int n) {
@@ -157,5 +181,5 @@ extern "C" int sir_profile_collect(sir_handle* h, double* total_ms, int64_t* lau
         h->prof_free.push_back(r.e1);
     }
     h->prof_pending.clear();
-    return SIR_OK;
+    return check_status_impl(h, nullptr, "sir_profile_collect");   // the host has synchronised anyway: surface a timed-out recurrence
 }

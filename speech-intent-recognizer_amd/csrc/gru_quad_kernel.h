@@ -71,7 +71,8 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     // wfrag0/1 (optional): prep_whh_quad_kernel output for direction 0 / 1
     // yplanes (optional): bf16x3 planes [3][B * S][512] of y, the A operand of the next layer's input projection
     // dbg (timing experiments only, results invalid): bit 0 = do not wait for the granules, bit 1 = skip the MFMAs,
-    // bit 2 = skip publish + receive
+    // bit 2 = skip publish + receive; fault injection for the status-word test: bit 3 = quarter 3 never publishes (its
+    // peers time out), bit 4 = spin limit 4096 instead of 2^22 (so that the injected timeout takes milliseconds)
     extern __shared__ __attribute__((aligned(16))) unsigned char qlds[];
     const int q = blockIdx.x, cluster = blockIdx.y;
     const int dir = cluster & 1, grp = cluster >> 1;
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     const int frag_off = n * GQ_ROWB + kg * 16;              // this lane's chunk inside a k-step of an h plane row
     // receive role: thread = (utterance rn, 4-unit group ru4) of each of the three other quarters
     const int rn = tid >> 4, ru4 = tid & 15;
+    bool timed_out = false;
 
     for (int step = 0; step < S; ++step) {
         const int t = dir ? (S - 1 - step) : step;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
             *reinterpret_cast<uint2*>(d + GQ_PLANEB) = pm;
             *reinterpret_cast<uint2*>(d + 2 * GQ_PLANEB) = pl;
         }
-        if (!(dbg & 4)) {
+        if (!(dbg & 4) && !((dbg & 8) && q == 3)) {
             unsigned long long* gs = xc + (((size_t)(step & 1) * 4 + q) * GQ_NU + n) * GQ_UQ + (u0 - q * GQ_UQ);
             const unsigned long long tag = (unsigned long long)(unsigned)(step + 1) << 48;
             const unsigned hh_[4] = {ph.x & 0xFFFFu, ph.x >> 16, ph.y & 0xFFFFu, ph.y >> 16};
@@ -225,9 +227,13 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
                 for (int qi = 0; qi < 3; ++qi)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) ok = ok && ((v[qi][j] >> 48) == want);
-                if (ok || (dbg & 1)) break;
+                if (ok || (dbg & 1) || timed_out) break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > GQ_SPIN_LIMIT) { __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if (++spins > ((dbg & 16) ? 4096u : GQ_SPIN_LIMIT)) {      // give up for good: later steps do not spin again
+                    __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    timed_out = true;
+                    break;
+                }
             }
 #pragma unroll
             for (int qi = 0; qi < 3; ++qi) {

@@ -282,11 +282,11 @@ if (occ)
                        w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024); }
     { SirProfScope prof(h, SIR_K_GRU0, st);
     if (gru_variant == 2) {
-        const int rc = sir_launch_gru_quad(st, false, gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S, nullptr, gxb, gfl,
+        const int rc = sir_launch_gru_quad(st, false, gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S, nullptr, gxb, h->status,
                                            fuse_y0 ? xs : nullptr, wht, (unsigned char*)wht + (size_t)768 * 256 * 6);
         if (rc != SIR_OK) return rc;
     } else if (gru_variant == 1) {
-        const int rc = sir_launch_gru_pair(st, false, gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S, nullptr, gxb, gfl);
+        const int rc = sir_launch_gru_pair(st, false, gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S, nullptr, gxb, gfl, h->status);
         if (rc != SIR_OK) return rc;
     } else
     hipLaunchKernelGGL(gru_recurrence_kernel<false>, rgrid, dim3(GRU_THREADS), GRU_LDS_BYTES, st, gi, wht, w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S,
@@ -301,11 +301,11 @@ if (occ)
                        w->gru_b_ih[2], w->gru_b_ih[3], gi, 1536, M, 768, 512); }
     { SirProfScope prof(h, SIR_K_GRU1, st);
     if (gru_variant == 2) {
-        const int rc = sir_launch_gru_quad(st, false, gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], y1, B, S, nullptr, gxb, gfl,
+        const int rc = sir_launch_gru_quad(st, false, gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], y1, B, S, nullptr, gxb, h->status,
                                            nullptr, (unsigned char*)wht + (size_t)2 * 768 * 256 * 6, (unsigned char*)wht + (size_t)3 * 768 * 256 * 6);
         if (rc != SIR_OK) return rc;
     } else if (gru_variant == 1) {
-        const int rc = sir_launch_gru_pair(st, false, gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], y1, B, S, nullptr, gxb, gfl);
+        const int rc = sir_launch_gru_pair(st, false, gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], y1, B, S, nullptr, gxb, gfl, h->status);
         if (rc != SIR_OK) return rc;
     } else
     hipLaunchKernelGGL(gru_recurrence_kernel<false>, rgrid, dim3(GRU_THREADS), GRU_LDS_BYTES, st, gi, wht + (size_t)2 * 768 * 256, w->gru_b_hh[2],

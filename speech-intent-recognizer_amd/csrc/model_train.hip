@@ -225,6 +225,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     float *scale = p.bn, *shift = p.bn + 224, *smean = p.bn + 448, *sinv = p.bn + 672;
 
     {   // all weight re-layouts of this step, the backward's included (the weights do not change before it runs)
+        SirProfScope prof(h, SIR_K_T_PREP, st);
         PrepJobs pj{};
         int nj = 0, blocks = 0;
         auto add = [&](int kind, const float* src, void* dst, int a, int b, int nblk) {
@@ -249,6 +250,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
 
     // conv1 block: statistics pass (recompute), finalize, then the fused conv+BN+ReLU+pool pass
     {
+        SirProfScope prof(h, SIR_K_T_CONV1, st);
         const dim3 g1(d.c1gx, d.c1gy, B);
         if (conv1_moments) {                           // statistics from 54 moments of the input, no conv1 recompute
             const int tiles = d.c1gx * d.c1gy;
@@ -272,12 +274,14 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     // conv2 block: raw conv + partial statistics on MFMA, finalize, BN+ReLU+pool
     {
         constexpr size_t lds = conv_bf16x6_lds_bytes(4, 2);
+        { SirProfScope prof(h, SIR_K_T_CONV2, st);
         if (sir_conv_ns())
         hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 2, 0, 3, false>), dim3(d.c2gx, 1, B), dim3(256), conv_bf16x6_lds_bytes(4, 2, false), st, (const float*)p.a1,
                            (const unsigned short*)p.wcb2, (const float*)nullptr, (const float*)nullptr, p.z2, 32, d.wp1, 16, d.wp2, p.stats);
         else
         hipLaunchKernelGGL((conv3x3_bf16x6_kernel<32, 64, 4, 2, 2, 2>), dim3(d.c2gx, 1, B), dim3(256), lds, st, (const float*)p.a1,
-                           (const unsigned short*)p.wcb2, (const float*)nullptr, (const float*)nullptr, p.z2, 32, d.wp1, 16, d.wp2, p.stats);
+                           (const unsigned short*)p.wcb2, (const float*)nullptr, (const float*)nullptr, p.z2, 32, d.wp1, 16, d.wp2, p.stats); }
+        SirProfScope prof(h, SIR_K_T_BN2, st);
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, d.c2gx * B, 64,
                            (double)B * 32 * d.wp1, w->bn_w[1], w->bn_b[1], bn_running_mean[1], bn_running_var[1], bn_momentum,
                            scale + 32, shift + 32, smean + 32, sinv + 32);
@@ -286,12 +290,14 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     }
     {
         constexpr size_t lds = conv_bf16x6_lds_bytes(2, 4);
+        { SirProfScope prof(h, SIR_K_T_CONV3, st);
         if (sir_conv_ns())
         hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 2, 0, 3, true>), dim3(d.c3fx, 1, B), dim3(256), conv_bf16x6_lds_bytes(2, 2), st, (const float*)p.a2,
                            (const unsigned short*)p.wcb3, (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats);
         else
         hipLaunchKernelGGL((conv3x3_bf16x6_kernel<64, 128, 2, 4, 2, 2>), dim3(d.c3gx, 1, B), dim3(256), lds, st, (const float*)p.a2,
-                           (const unsigned short*)p.wcb3, (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats);
+                           (const unsigned short*)p.wcb3, (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats); }
+        SirProfScope prof(h, SIR_K_T_BN3, st);
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, (sir_conv_ns() ? d.c3fx : d.c3gx) * B, 128,
                            (double)B * 16 * d.wp2, w->bn_w[2], w->bn_b[2], bn_running_mean[2], bn_running_var[2], bn_momentum,
                            scale + 96, shift + 96, smean + 96, sinv + 96);
@@ -302,26 +308,32 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
 
     const int M = B * S;
     const dim3 ggrid(768 / GB_N, (M + GB_M - 1) / GB_M, 2);
+    { SirProfScope prof(h, SIR_K_T_GEMM_IH0, st);
     hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, (const float*)p.x0, 1024, p.xs, (size_t)M, 1024);
     SIR_HIP_TRY(launch_gemm_nt_bf16x6(st, sir_gemm_bf16x6_gen(), (const unsigned short*)p.xs, (const unsigned short*)p.wsl0,
-                       (const unsigned short*)(p.wsl0 + (size_t)3 * 768 * 1024), w->gru_b_ih[0], w->gru_b_ih[1], p.gi, 1536, M, 768, 1024));
+                       (const unsigned short*)(p.wsl0 + (size_t)3 * 768 * 1024), w->gru_b_ih[0], w->gru_b_ih[1], p.gi, 1536, M, 768, 1024)); }
+    { SirProfScope prof(h, SIR_K_T_GRU0, st);
     rc = sir_gru_variant() == 2
-             ? sir_launch_gru_quad(st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0, p.gxb, p.gfl)
-             : sir_launch_gru_pair(st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0, p.gxb, p.gfl);
+             ? sir_launch_gru_quad(st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0, p.gxb, h->status)
+             : sir_launch_gru_pair(st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0, p.gxb, p.gfl, h->status); }
     if (rc != SIR_OK) return rc;
     const float* y0in = p.y0;
     if (dropout_p > 0.0f) {
+        SirProfScope prof(h, SIR_K_T_DROPOUT, st);
         hipLaunchKernelGGL(dropout_kernel, dim3(grid_for((size_t)M * 512)), dim3(256), 0, st, p.y0, p.y0d, (size_t)M * 512,
                            dropout_p, (unsigned long long)dropout_seed);
         y0in = p.y0d;
     }
+    { SirProfScope prof(h, SIR_K_T_GEMM_IH1, st);
     hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, y0in, 512, p.xs, (size_t)M, 512);
     SIR_HIP_TRY(launch_gemm_nt_bf16x6(st, sir_gemm_bf16x6_gen(), (const unsigned short*)p.xs, (const unsigned short*)p.wsl1,
-                       (const unsigned short*)(p.wsl1 + (size_t)3 * 768 * 512), w->gru_b_ih[2], w->gru_b_ih[3], p.gi, 1536, M, 768, 512));
+                       (const unsigned short*)(p.wsl1 + (size_t)3 * 768 * 512), w->gru_b_ih[2], w->gru_b_ih[3], p.gi, 1536, M, 768, 512)); }
+    { SirProfScope prof(h, SIR_K_T_GRU1, st);
     rc = sir_gru_variant() == 2
-             ? sir_launch_gru_quad(st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1, p.gxb, p.gfl)
-             : sir_launch_gru_pair(st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1, p.gxb, p.gfl);
+             ? sir_launch_gru_quad(st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1, p.gxb, h->status)
+             : sir_launch_gru_pair(st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1, p.gxb, p.gfl, h->status); }
     if (rc != SIR_OK) return rc;
+    SirProfScope prof_head(h, SIR_K_T_HEAD, st);
     hipLaunchKernelGGL(attention_pool_kernel, dim3(B), dim3(256), 0, st, p.y1, w->attn_w, w->attn_b, p.ctx, S, w->fc_w,
                        w->fc_b, w->num_classes, logits, (long long*)nullptr);
     KCHECK();
@@ -332,6 +344,7 @@ extern "C" int sir_ce_loss(sir_handle* h, const float* logits, const int64_t* la
                            float* loss, float* dlogits, float grad_scale, void* stream_) {
     if (!h || !logits || !labels || !loss) { sir_set_error("sir_ce_loss: NULL argument"); return SIR_EINVAL; }
     if (batch < 1 || num_classes < 1) { sir_set_error("sir_ce_loss: bad shape"); return SIR_EINVAL; }
+    SirProfScope prof(h, SIR_K_CE, (hipStream_t)stream_);
     hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, logits, (const long long*)labels, batch,
                        num_classes, loss, dlogits, grad_scale);
     KCHECK();
@@ -390,11 +403,12 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
 
     if (part != SIR_BWD_CNN) {
     // ---- head: fc + attention pooling ----------------------------------------------------
+    { SirProfScope prof(h, SIR_K_B_HEAD, st);
     hipLaunchKernelGGL(fc_wgrad_kernel, dim3(C, 2), dim3(256), 0, st, dlogits, (const float*)p.ctx, g->fc_w, g->fc_b, B, C);
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, st, dlogits, w->fc_w, (const float*)p.y1, w->attn_w, w->attn_b,
                        p.dy1, daw_part, dab_part, S, C);
     hipLaunchKernelGGL(colsum_kernel, dim3(8), dim3(256), 0, st, (const float*)daw_part, B, 512, 512, g->attn_w);
-    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, st, (const float*)dab_part, B, 1, 1, g->attn_b);
+    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, st, (const float*)dab_part, B, 1, 1, g->attn_b); }
     KCHECK();                                          // (W_hh re-layout p.wr4: train_prep_kernel of the forward)
 
     // ---- GRU layers, top down ----------------------------------------------------------------
@@ -405,16 +419,18 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         const float* xin = layer ? y0in : p.x0;
         const int in_sz = layer ? 512 : 1024;
 static const int gru_bwd_variant = getenv("SIR_GRU_BWD_VARIANT") ? atoi(getenv("SIR_GRU_BWD_VARIANT")) : 1;
+        { SirProfScope prof(h, layer ? SIR_K_B_GRU1 : SIR_K_B_GRU0, st);
         if (gru_bwd_variant == 1) {
             rc = sir_launch_gru_bwd_pair(st, dy, gates, yout, w->gru_w_hh[2 * layer], w->gru_w_hh[2 * layer + 1], p.dgi, p.dgh, bsum_i, bsum_h,
-                                         B, S, p.gxb, p.gfl);
+                                         B, S, p.gxb, h->status);
             if (rc != SIR_OK) return rc;
         } else
         hipLaunchKernelGGL(gru_bwd_kernel, dim3((B + GRU_BBW - 1) / GRU_BBW, 2), dim3(1024), 0, st, dy, gates, yout, (const float*)(p.wr4 + (size_t)2 * layer * 768 * 256),
                            p.dgi, p.dgh, bsum_i, bsum_h, B, S);
         // bias gradients first: bsum_* alias the slab area used below
         hipLaunchKernelGGL(gru_bias_colsum_kernel, dim3(24, 2), dim3(256), 0, st, (const float*)bsum_i, (const float*)bsum_h, B,
-                           g->gru_b_ih[2 * layer], g->gru_b_ih[2 * layer + 1], g->gru_b_hh[2 * layer], g->gru_b_hh[2 * layer + 1]);
+                           g->gru_b_ih[2 * layer], g->gru_b_ih[2 * layer + 1], g->gru_b_hh[2 * layer], g->gru_b_hh[2 * layer + 1]); }
+        { SirProfScope prof(h, layer ? SIR_K_B_DW1 : SIR_K_B_DW0, st);
         static const int tn_x6 = getenv("SIR_GEMM_TN_X6") ? atoi(getenv("SIR_GEMM_TN_X6")) : 1;
         if (tn_x6) {
             // all four weight-gradient GEMMs of the layer (2 directions x {W_ih, W_hh}) in one bf16x6 launch
@@ -463,7 +479,9 @@ static const int gru_bwd_variant = getenv("SIR_GRU_BWD_VARIANT") ? atoi(getenv("
             launch_tn(st, d, p.dgh + dir * 768, 1536, yout + dir * 256, 512, g->gru_w_hh[gi_idx], p.slab, 768, 256, M, S,
                       dir ? 1 : -1);
         }
+        }
         // gradient wrt the layer input: dgi [M][1536] x [W_ih; W_ih_reverse] [1536][in]
+        SirProfScope prof(h, layer ? SIR_K_B_DX1 : SIR_K_B_DX0, st);
         float* dxin = layer ? p.dy0 : p.dx0;
 static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6")) : 1;
         if (nn_x6) {
@@ -508,6 +526,7 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
         const size_t npix = (size_t)B * 8 * d.wp3;
         const int nblk = (int)((npix + ppb - 1) / ppb);
         int nfin = nblk;
+        { SirProfScope prof(h, SIR_K_B_BN3, st);
         if (bn_reduce_pooled) {                       // from the pooled activations x0 (GRU layout) instead of z3
             const int rows = B * d.wp3, rpb = 16;
             nfin = (rows + rpb - 1) / rpb;
@@ -521,7 +540,7 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
                            (double)B * 16 * d.wp2, g->bn_w[2], g->bn_b[2], mdy + 96, mdyx + 96);
         hipLaunchKernelGGL(bn_bwd_dz_kernel<true>, dim3(grid_for((size_t)B * 8 * ((d.wp2 + 1) / 2) * 32)), dim3(256), 0, st, (const float*)p.z3,
                            (const float*)p.dx0, scale + 96, shift + 96, smean + 96, sinv + 96, mdy + 96, mdyx + 96, p.dz3, B, 16,
-                           d.wp2, 128, 8, d.wp3);
+                           d.wp2, 128, 8, d.wp3); }
         const int Wk = (d.wp2 + 1) & ~1;
         const size_t lds = ((size_t)Wk * 128 + 3 * (size_t)(Wk + 2) * 64) * 4;
         static bool attr3 = false;
@@ -532,6 +551,7 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
         if (lds > 160 * 1024) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
         static const int wgrad_x6 = getenv("SIR_WGRAD_X6") ? atoi(getenv("SIR_WGRAD_X6")) : 1;
         int nslab3 = d.wg3_blocks;
+        { SirProfScope prof(h, SIR_K_B_WGRAD3, st);
         if (wgrad_x6) {
             static bool attrx = false;
             if (!attrx) {
@@ -552,7 +572,8 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
                                (const float*)p.slab, nslab3, 9 * 128 * 64 / 4, part);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 128 * 64 + 255) / 256), dim3(256), 0, st, (const float*)part, WGR_PARTS, 64, 128,
                                g->conv_w[2]);
-        }
+        } }
+        SirProfScope prof(h, SIR_K_B_DGRAD3, st);
         // (data-gradient weights p.wcb3t: train_prep_kernel of the forward)
         constexpr size_t ldsd = conv_bf16x6_lds_bytes(2, 4);
         if (sir_conv_ns())
@@ -570,6 +591,7 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
         const int ppb = 64;
         const size_t npix = (size_t)B * 16 * d.wp2;
         const int nblk = (int)((npix + ppb - 1) / ppb);
+        { SirProfScope prof(h, SIR_K_B_BN2, st);
         if (bn_reduce_pooled)
         hipLaunchKernelGGL(bn_bwd_reduce_pooled_kernel, dim3(nblk), dim3(256), 0, st, (const float*)p.a2, (const float*)p.da2,
                            (const float*)p.z2, w->bn_w[1], w->bn_b[1], scale + 32, shift + 32, smean + 32, sinv + 32, p.stats, B, 32,
@@ -581,7 +603,7 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
                            (double)B * 32 * d.wp1, g->bn_w[1], g->bn_b[1], mdy + 32, mdyx + 32);
         hipLaunchKernelGGL(bn_bwd_dz_kernel<false>, dim3(grid_for((size_t)B * 16 * ((d.wp1 + 1) / 2) * 16)), dim3(256), 0, st, (const float*)p.z2,
                            (const float*)p.da2, scale + 32, shift + 32, smean + 32, sinv + 32, mdy + 32, mdyx + 32, p.dz2, B, 32,
-                           d.wp1, 64, 16, d.wp2);
+                           d.wp1, 64, 16, d.wp2); }
         const int Wk = (d.wp1 + 1) & ~1;
         const size_t lds = ((size_t)Wk * 64 + 3 * (size_t)(Wk + 2) * 32) * 4;
         static bool attr2 = false;
@@ -592,6 +614,7 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
         if (lds > 160 * 1024) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
         static const int wgrad_x6b = getenv("SIR_WGRAD_X6") ? atoi(getenv("SIR_WGRAD_X6")) : 1;
         int nslab2 = d.wg2_blocks;
+        { SirProfScope prof(h, SIR_K_B_WGRAD2, st);
         if (wgrad_x6b) {
             static bool attrx2 = false;
             if (!attrx2) {
@@ -612,7 +635,8 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
                                (const float*)p.slab, nslab2, 9 * 64 * 32 / 4, part);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 32 + 255) / 256), dim3(256), 0, st, (const float*)part, WGR_PARTS, 32, 64,
                                g->conv_w[1]);
-        }
+        } }
+        SirProfScope prof(h, SIR_K_B_DGRAD2, st);
         // (data-gradient weights p.wcb2t: train_prep_kernel of the forward)
         constexpr size_t ldsd = conv_bf16x6_lds_bytes(4, 2);
         if (sir_conv_ns())
@@ -627,6 +651,7 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
     }
     // ---- conv1 block (recomputed) ------------------------------------------------------------
     {
+        SirProfScope prof(h, SIR_K_B_CONV1, st);
         const dim3 g1(d.c1gx, d.c1gy, B);
         const int nblk = d.c1gx * d.c1gy * B;
         if (conv1_moments) {
@@ -673,6 +698,7 @@ extern "C" int sir_adam_step(sir_handle* h, int n_tensors, float* const* params,
     ts.first_block[n_tensors] = blocks;
     ts.count = n_tensors;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    SirProfScope prof(h, SIR_K_ADAM, (hipStream_t)stream_);
     hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, ts, lr, beta1, beta2, eps, weight_decay,
                        (float)bc1, (float)sqrt(bc2));
     KCHECK();

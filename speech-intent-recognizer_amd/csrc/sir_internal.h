@@ -16,7 +16,13 @@
 // kernels (or kernel groups) of the path, for sir_profile_*
 enum SirKernelId {
     SIR_K_FEAT_FRAMES = 0, SIR_K_FEAT_NORM, SIR_K_PREP, SIR_K_CONV1, SIR_K_CONV2, SIR_K_CONV3,
-    SIR_K_GEMM_IH0, SIR_K_GRU0, SIR_K_GEMM_IH1, SIR_K_GRU1, SIR_K_ATTN, SIR_K_FC, SIR_K_COUNT
+    SIR_K_GEMM_IH0, SIR_K_GRU0, SIR_K_GEMM_IH1, SIR_K_GRU1, SIR_K_ATTN, SIR_K_FC,
+    // training step (model_train.hip): forward groups, loss, backward groups, optimizer
+    SIR_K_T_PREP, SIR_K_T_CONV1, SIR_K_T_CONV2, SIR_K_T_BN2, SIR_K_T_CONV3, SIR_K_T_BN3, SIR_K_T_GEMM_IH0, SIR_K_T_GRU0,
+    SIR_K_T_DROPOUT, SIR_K_T_GEMM_IH1, SIR_K_T_GRU1, SIR_K_T_HEAD, SIR_K_CE,
+    SIR_K_B_HEAD, SIR_K_B_GRU1, SIR_K_B_DW1, SIR_K_B_DX1, SIR_K_B_GRU0, SIR_K_B_DW0, SIR_K_B_DX0,
+    SIR_K_B_BN3, SIR_K_B_WGRAD3, SIR_K_B_DGRAD3, SIR_K_B_BN2, SIR_K_B_WGRAD2, SIR_K_B_DGRAD2, SIR_K_B_CONV1, SIR_K_ADAM,
+    SIR_K_COUNT
 };
 
 struct SirProfRec { int id; hipEvent_t e0, e1; };
@@ -51,6 +57,9 @@ struct sir_handle {
     int* mel_start;     // [64] first FFT bin of each filter
     int max_taps;
     std::vector<sir_resample_table> resample_tables;   // built on first use of a rate pair
+    // device word set to 1 by a GRU recurrence kernel whose inter-workgroup exchange timed out (its results are then
+    // invalid); zeroed at creation, read and cleared by sir_check_status / sir_profile_collect
+    unsigned int* status;
 };
 
 void sir_set_error(const char* fmt, ...);
@@ -92,7 +101,7 @@ size_t sir_train_workspace_bytes_impl(int batch, int t_frames);
 size_t sir_gru_pair_xbuf_bytes(int batch);
 size_t sir_gru_pair_flag_bytes(int batch);
 int sir_launch_gru_pair(hipStream_t st, bool save, const float* gi, const float* whh0, const float* whh1, const float* bhh0,
-                        const float* bhh1, float* y, int B, int S, float* gates, float* xbuf, unsigned int* flags);
+                        const float* bhh1, float* y, int B, int S, float* gates, float* xbuf, unsigned int* flags, unsigned int* status);
 
 // features.hip
 int sir_features_launch(sir_handle* h, const void* wave, int wave_dtype, int64_t wave_stride,
@@ -111,7 +120,7 @@ void sir_prep_whh_quad(hipStream_t st, const float* whh, void* frag);     // -> 
 int sir_gru_variant();
 // paired-workgroup GRU backward recurrence (gru_pair.hip); SIR_GRU_BWD_VARIANT=0 selects the streaming kernel
 int sir_launch_gru_bwd_pair(hipStream_t st, const float* dy, const float* gates, const float* y, const float* whh0, const float* whh1,
-                            float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S, float* xbuf, unsigned int* flags);
+                            float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S, float* xbuf, unsigned int* status);
 // conv1 on the f32 matrix pipe (SIR_CONV1_MFMA, default 1) instead of the direct VALU form
 int sir_conv1_mfma();
 // convolution generation (SIR_CONV_NS, default 1 = output channels split over the waves)

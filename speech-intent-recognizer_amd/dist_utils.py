@@ -62,6 +62,8 @@ def broadcast_module_(module, src=0):
     if world_size() > 1:
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src)
+        from . import ops                       # writes through .data do not bump torch's version counters
+        ops.bump_weights_epoch()
     return module
 
 

@@ -38,10 +38,18 @@ class CNNAudioGRU(nn.Module):
         self.fc = nn.Linear(2 * GRU_HIDDEN, num_classes)
         self._ws = ops.Workspace()
         self._sir_wcache = None
+        self._sir_token = ops.new_model_token()
 
     def _apply(self, fn, *args, **kwargs):
         self._sir_wcache = None             # .to()/.cuda()/.float() may move the storage
+        self._sir_token = ops.new_model_token()
         return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._sir_wcache = None             # assign=True swaps the tensors themselves
+        self._sir_token = ops.new_model_token()
+        return out
 
     def forward(self, x):
         """x: [B, 64, T] or [B, 1, 64, T] float32 on the GPU -> logits [B, num_classes]."""

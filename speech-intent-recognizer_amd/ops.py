@@ -5,6 +5,7 @@ gets ``data_ptr()``s plus the current stream.  No arithmetic is done in Python
 and nothing falls back to ``torch.nn`` compute.
 """
 import ctypes as C
+import itertools
 
 import torch
 
@@ -60,36 +61,67 @@ def cached_weights(mod):
     if cache is None:
         cache = weights_struct(mod)
         mod._sir_wcache = cache
+        mod._sir_wptrs = None
     return cache
 
 
 _weights_epoch = [1]
+_model_tokens = itertools.count(1)
+
+
+def new_model_token():
+    """Process-unique id of one set of weights: ``CNNAudioGRU`` takes one in ``__init__`` and a fresh one whenever its
+    storage or contents are replaced wholesale (``_apply``, ``load_state_dict``).  ``id(module)`` is NOT such an id: a
+    freed module's address is reused by the next one built in the same place."""
+    return next(_model_tokens)
 
 
 def bump_weights_epoch():
     """Called by everything that rewrites parameters/buffers behind torch's back (the HIP Adam step, the
-    training forward's running-statistics update), so that cached derived weight layouts are rebuilt."""
+    training forward's running-statistics update, ``broadcast_module_``'s writes through ``.data``), so that
+    cached derived weight layouts are rebuilt."""
     _weights_epoch[0] += 1
 
 
-def weights_version(mod, keep):
-    """Non-zero fingerprint of the weights: global epoch + torch's in-place version counters + storage."""
-    v = _weights_epoch[0] << 40
-    for t in keep:
-        v += t._version
-    return (v + (id(mod) & 0xFFFFF)) & 0xFFFFFFFFFFFFFFFF or 1
+def weights_version(mod, keep, workspace=None):
+    """Non-zero 64-bit fingerprint of (the global epoch, the model's token, torch's in-place version counters, the
+    storage addresses of every parameter / buffer, the generation of the workspace that holds the prepared layouts).
+    Two different models, a moved or reloaded model, or a re-allocated workspace can therefore never present the
+    library with the version under which another set of weights was prepared."""
+    token = getattr(mod, "_sir_token", None)
+    if token is None:
+        token = mod._sir_token = new_model_token()
+    ptrs = getattr(mod, "_sir_wptrs", None)
+    if ptrs is None or len(ptrs) != len(keep):
+        ptrs = mod._sir_wptrs = tuple(t.data_ptr() for t in keep)      # constant while the pointer struct is cached
+    key = (_weights_epoch[0], token, workspace.generation if workspace is not None else 0,
+           tuple(t._version for t in keep), ptrs)
+    return (hash(key) & 0xFFFFFFFFFFFFFFFF) or 1
 
 
 class Workspace:
-    """Grow-only device scratch, 256-byte aligned (torch's caching allocator aligns to 512)."""
+    """Grow-only device scratch, 256-byte aligned (torch's caching allocator aligns to 512).  ``generation`` counts the
+    allocations: prepared weight layouts live inside the buffer, so a new buffer (even at the old address) invalidates
+    them -- ``weights_version`` folds the generation in."""
+    _generations = itertools.count(1)
 
     def __init__(self):
         self.buf = None
+        self.generation = 0
 
     def get(self, nbytes, device):
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
             self.buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+            self.generation = next(Workspace._generations)
         return self.buf
+
+
+def check_status():
+    """Raise ``SirError`` if a GRU recurrence launched since the last check timed out in its inter-workgroup exchange
+    (``sir_check_status``: its outputs were invalid).  Host-synchronous on the current stream -- call it where the host
+    waits anyway (end of an epoch, after a batch of predictions has been copied back)."""
+    lib = _native.lib()
+    _native.check(lib.sir_check_status(get_featurizer().handle, _native.current_stream_ptr()), "sir_check_status")
 
 
 def _as_features(x):
@@ -118,7 +150,7 @@ def model_infer(mod, x, workspace, want_argmax=False, debug=None):
     w, keep = cached_weights(mod)
     logits = torch.empty((bsz, w.num_classes), dtype=torch.float32, device=x.device)
     amax = torch.empty((bsz,), dtype=torch.int64, device=x.device) if want_argmax else None
-    lib.sir_model_set_weights_version(h, weights_version(mod, keep))
+    lib.sir_model_set_weights_version(h, weights_version(mod, keep, workspace))
     rc = lib.sir_model_infer(h, C.byref(w), x.data_ptr(), bsz, t, logits.data_ptr(),
                              amax.data_ptr() if amax is not None else None, ws.data_ptr(), ws.numel(),
                              _native.current_stream_ptr())

@@ -4,9 +4,15 @@ Same constructor, ``__len__`` and ``__getitem__(idx) -> (FloatTensor[64, 200], i
 file format and the same in-band error conventions (label fallback id 0, zero spectrogram on a
 failed clip).  Items are CPU tensors served from the feature cache that
 ``scripts.precompute_features`` writes with the HIP kernels, so the object is fork/pickle-safe for
-``DataLoader`` worker processes and never owns a HIP context itself.  A cache miss is computed on
-the GPU when ``__getitem__`` runs in the main process (``num_workers=0``); inside a worker process
-(where a forked HIP context must not be used) it follows the reference's failure path: logged, zeros.
+``DataLoader`` worker processes and never owns a HIP context itself.
+
+Cache misses (``use_cache=False``, a missing or partial cache file): the reference computes them with torchaudio
+inside the worker that hits them (dataset.py:97-98, :117-158).  A forked worker must not touch the HIP context, so
+here EVERY path of the CSV that is not in the cache is extracted up front, in the constructor, in the main process,
+through the batched GPU path (``AudioFeatureExtractor.extract_batch``, a few hundred clips per launch) into the
+in-memory cache the workers inherit.  Only a clip that genuinely fails (missing file, undecodable, too short) becomes
+the reference's zero spectrogram.  A miss that still reaches a worker (the file appeared after construction, or the
+dataset was built without a GPU) raises instead of silently training on zeros.
 """
 import json
 import logging
@@ -65,7 +71,47 @@ class FSCIntentDataset(Dataset):
         self.freq_mask_param = 10
         self._paths = self.data["path"].tolist()
         self._labels = self.data["label"].tolist()
+        self.prefetch_missing()
         logger.info(f"Initialized dataset with {len(self.data)} samples, {len(self.label_map)} classes")
+
+    def missing_paths(self):
+        """CSV paths (unique, in order) that neither the disk cache nor the in-memory cache holds."""
+        seen, out = set(), []
+        for p in self._paths:
+            if p not in seen and p not in self.features_dict and p not in self.in_memory_cache:
+                seen.add(p)
+                out.append(p)
+        return out
+
+    def prefetch_missing(self, batch_size=256):
+        """Main process only: extract every uncached clip on the GPU in batches (what the reference does one clip at a
+        time inside its workers).  Failed clips get the reference's zero spectrogram (dataset.py:121-123, :156-158).
+        Without a HIP device nothing is done here and a later miss follows ``extract_features``.  Returns the number of
+        clips extracted."""
+        if get_worker_info() is not None:
+            return 0
+        missing = self.missing_paths()
+        if not missing or not torch.cuda.is_available():
+            return 0
+        from sir_amd.scripts.precompute_features import AudioFeatureExtractor
+        extractor = AudioFeatureExtractor(self.sample_rate, self.n_mels, 1024, 512)
+        logger.info(f"{len(missing)} clips are not in the feature cache: extracting them on the GPU")
+        failed = 0
+        for start in range(0, len(missing), batch_size):
+            chunk = missing[start:start + batch_size]
+            try:
+                feats = extractor.extract_batch(chunk, max_duration=5.0)
+            except Exception as e:                      # in-band error convention: log, zeros
+                logger.error(f"Error processing a batch of {len(chunk)} clips: {str(e)}")
+                feats = [None] * len(chunk)
+            for p, f in zip(chunk, feats):
+                if f is None:
+                    failed += 1
+                    f = torch.zeros((self.n_mels, self.mel_spec_length))
+                self.in_memory_cache[p] = f
+        if failed:
+            logger.error(f"{failed} of {len(missing)} uncached clips could not be processed (zero spectrograms)")
+        return len(missing)
 
     def __len__(self):
         return len(self.data)
@@ -98,14 +144,17 @@ class FSCIntentDataset(Dataset):
                 logger.error(f"File not found: {audio_path}")
                 return zeros
             if get_worker_info() is not None:
-                logger.error(f"{audio_path}: not in the feature cache and the GPU cannot be used from a "
-                             "DataLoader worker process; run scripts.precompute_features or use num_workers=0")
-                return zeros
+                # (not reachable when the dataset was built on a GPU box: the constructor extracted every miss)
+                raise RuntimeError(f"{audio_path}: not in the feature cache and the GPU cannot be used from a DataLoader "
+                                   "worker process; call dataset.prefetch_missing() in the main process, run "
+                                   "scripts.precompute_features, or use num_workers=0")
             from sir_amd.scripts.precompute_features import AudioFeatureExtractor
             if not hasattr(self, "_extractor"):
                 self._extractor = AudioFeatureExtractor(self.sample_rate, self.n_mels, 1024, 512)
             feat = self._extractor.extract_features(audio_path, max_duration=5.0)
             return feat if feat is not None else zeros
+        except RuntimeError:
+            raise
         except Exception as e:
             logger.error(f"Error processing {audio_path}: {str(e)}")
             return zeros

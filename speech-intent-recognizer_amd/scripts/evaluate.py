@@ -42,6 +42,8 @@ def predict_loader(model, loader, device):
     if not preds:
         return [], []
     pipe.synchronize()
+    from sir_amd import ops
+    ops.check_status()                    # a timed-out GRU recurrence would have produced invalid predictions: raise
     return torch.cat(preds).cpu().numpy(), torch.cat(labels).numpy()
 
 

@@ -83,11 +83,15 @@ class AudioFeatureExtractor:
                     logger.error(f"Error processing {audio_paths[i]}: clip too short for reflect padding")
         return out
 
-    def _features_of_group(self, datas, channels, sr, max_duration):
+    def waveforms_of_group(self, datas, channels, sr, max_duration):
+        """Decoded clips of one (channels, rate, sample type) group -> (wave [N, L] on the GPU, lengths int32 [N] on the
+        GPU): mono mix-down, resampling to ``self.sample_rate`` and truncation to ``max_duration`` as
+        precompute_features.py:50-61 does per file.  PCM16 mono clips already at the target rate stay int16 (the
+        feature kernel dequantises with torchaudio.load's 1/32768)."""
         fz = self._featurizer()
         dev = fz.device
         nfr = [int(d.numel()) // channels for d in datas]
-        host = torch.zeros((len(datas), max(nfr) * channels), dtype=datas[0].dtype).pin_memory()
+        host = torch.zeros((len(datas), max(max(nfr), 1) * channels), dtype=datas[0].dtype).pin_memory()
         for k, d in enumerate(datas):
             host[k, : nfr[k] * channels] = d[: nfr[k] * channels]
         wave = host.to(dev, non_blocking=True)
@@ -101,6 +105,11 @@ class AudioFeatureExtractor:
         wave = wave[:, :max_samples]
         if wave.stride(1) != 1 or (wave.stride(0) * wave.element_size()) % 16:
             wave = wave.contiguous()
+        return wave, lens
+
+    def _features_of_group(self, datas, channels, sr, max_duration):
+        fz = self._featurizer()
+        wave, lens = self.waveforms_of_group(datas, channels, sr, max_duration)
         host_lens = lens.cpu().tolist()
         ok = [n > self.n_fft // 2 for n in host_lens]
         frames = [fz.num_frames(n) for n in host_lens]

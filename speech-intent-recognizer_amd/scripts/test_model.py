@@ -18,6 +18,7 @@ import sys
 import numpy as np
 import torch
 
+from sir_amd import ops
 from sir_amd.models.models import CNNAudioGRU
 from sir_amd.scripts.precompute_features import AudioFeatureExtractor
 
@@ -105,7 +106,9 @@ def predict(model, audio_path, label_map, device, pad_to=MAX_LENGTH):
         mel_spec = mel_spec.to(device)
         with torch.no_grad():
             output = model(mel_spec)
-        return _result(output, {v: k for k, v in label_map.items()})
+        result = _result(output, {v: k for k, v in label_map.items()})
+        ops.check_status()
+        return result
     except Exception as e:
         logger.error(f"Error during prediction: {str(e)}")
         return None
@@ -125,6 +128,7 @@ def predict_many(model, audio_paths, label_map, device, pad_to=MAX_LENGTH):
         inv = {v: k for k, v in label_map.items()}
         for row, i in enumerate(keep):
             results[i] = _result(output[row:row + 1], inv)
+        ops.check_status()
         return results
     except Exception as e:
         logger.error(f"Error during prediction: {str(e)}")

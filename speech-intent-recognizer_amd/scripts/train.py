@@ -58,12 +58,19 @@ def train_epoch(model, train_loader, optimizer, criterion, device, scaler=None):
     """One epoch (train.py:72-118); returns the mean of the per-step losses.  ``scaler`` is accepted
     for signature compatibility: the HIP path always computes in fp32 (the parity target is the fp32
     CPU path), so no loss scaling is needed or applied."""
+    from sir_amd import ops, train_ops
     model.train()
     loss_fn = _loss_fn(criterion)
     losses = []
     pbar = tqdm(train_loader, desc="Training", disable=_quiet())
     for batch_idx, (mel, label) in enumerate(pbar):
         if mel is None or label is None or mel.size(0) == 0:
+            if train_ops.world_size() > 1:
+                # the other ranks are entering this step's gradient all-reduce: join it with a zero gradient and apply
+                # the same update (a bare `continue`, train.py:82-83, would leave them waiting for ever)
+                optimizer.zero_grad(set_to_none=True)
+                train_ops.zero_contribution_step(model)
+                optimizer.step()
             continue
         mel = mel.to(device, non_blocking=True)
         label = label.to(device, non_blocking=True)
@@ -78,16 +85,21 @@ def train_epoch(model, train_loader, optimizer, criterion, device, scaler=None):
                               "GPU": f"{torch.cuda.memory_allocated() / 1024 ** 2:.1f}MB"})
     if not losses:
         return 0.0
-    return torch.stack(losses).mean().item()          # one device->host sync per epoch
+    mean = torch.stack(losses).mean().item()          # one device->host sync per epoch
+    ops.check_status()                                # ... which is where a timed-out GRU recurrence is reported
+    return mean
 
 
 def train_epoch_waveforms(model, wave_loader, optimizer, criterion, device, t_pad=200, augment=None):
     """``train_epoch`` fed with RAW waveform batches: ``wave_loader`` yields ``(wave [B, L] float32 | int16, lengths int32
     [B] | None, label int64 [B])``; the log-mel features are computed on the GPU (BASELINE configs[2]: fused HIP feature
     extraction + forward/backward + Adam) one batch ahead of the training step on a side stream
-    (``sir_amd.pipeline.FeaturePrefetcher``).  ``augment(wave_batch_index, batch_size) -> dict`` may return the
-    featurizer's on-the-fly augmentation arguments (``shift``, ``noise_sigma``, ``noise_seed``, ``time_mask``,
-    ``freq_mask``: scripts/augment.py, dataset.py:160-176) for that batch.  Returns the mean of the per-step losses."""
+    (``sir_amd.pipeline.FeaturePrefetcher``).  Items may carry a fourth element, the lengths as a host list (what
+    ``WaveformStore.epoch_batches`` yields), so that augmentation parameters can be drawn without a device sync.
+    ``augment(wave_batch_index, batch_size, host_lengths | None) -> dict`` may return the featurizer's on-the-fly
+    augmentation arguments (``shift``, ``noise_sigma``, ``noise_seed``, ``time_mask``, ``freq_mask``: scripts/augment.py,
+    dataset.py:160-176) for that batch.  Returns the mean of the per-step losses."""
+    from sir_amd import ops
     from sir_amd.pipeline import FeaturePrefetcher
     model.train()
     loss_fn = _loss_fn(criterion)
@@ -95,12 +107,13 @@ def train_epoch_waveforms(model, wave_loader, optimizer, criterion, device, t_pa
     losses, pending = [], []
 
     def submit(idx, item):
-        wave, lengths, label = item
+        wave, lengths, label = item[:3]
+        host_lengths = item[3] if len(item) > 3 else None
         if wave is None or label is None or wave.size(0) == 0:
             return
         wave = wave.to(device, non_blocking=True)
         lengths = lengths.to(device, non_blocking=True) if lengths is not None else None
-        pre.kw = augment(idx, wave.size(0)) if augment is not None else {}
+        pre.kw = augment(idx, wave.size(0), host_lengths) if augment is not None else {}
         pre.submit(wave, lengths)
         pending.append(label.to(device, non_blocking=True))
 
@@ -121,13 +134,41 @@ def train_epoch_waveforms(model, wave_loader, optimizer, criterion, device, t_pa
         step()
     if not losses:
         return 0.0
-    return torch.stack(losses).mean().item()
+    mean = torch.stack(losses).mean().item()
+    ops.check_status()
+    return mean
+
+
+def make_waveform_augment(config, seed=0, epoch=0, rng=None):
+    """The ``augment`` callable of ``train_epoch_waveforms`` for the YAML keys of scripts/train.py: time shift + noise
+    (scripts/augment.py:98-135 gating, ``waveform_augment_prob``, default 0.7 as augment.py:98) when
+    ``waveform_augment`` is on, and the dataset's SpecAugment (dataset.py:105-106, :160-176, ``augment_prob``) always --
+    the cached-feature route applies that one in ``FSCIntentDataset.__getitem__``, the fused route has no dataset."""
+    import random
+    from sir_amd.scripts import augment as aug
+    rng = rng or random.Random((int(seed) << 20) ^ int(epoch))
+    wave_aug = bool(config.get("waveform_augment", False))
+    wave_prob = float(config.get("waveform_augment_prob", 0.7))
+    spec_prob = float(config.get("augment_prob", 0.5))
+
+    def fn(idx, bsz, host_lengths):
+        if host_lengths is None:
+            raise ValueError("waveform augmentation needs the clip lengths on the host (WaveformStore yields them)")
+        kw = {}
+        if wave_aug:
+            shift, sigma = aug.draw_batch_params(host_lengths, wave_prob, rng)
+            kw.update(shift=shift, noise_sigma=sigma, noise_seed=(int(seed) << 40) ^ (int(epoch) << 24) ^ int(idx))
+        if spec_prob > 0.0:
+            tm, fm = aug.draw_spec_masks([1 + n // 512 for n in host_lengths], spec_prob, rng=rng)
+            kw.update(time_mask=tm, freq_mask=fm)
+        return kw
+    return fn
 
 
 def validate(model, val_loader, criterion, device, scaler=None):
     """(avg_loss, accuracy) over the loader (train.py:120-155); under data parallelism the counts are
     summed over ranks."""
-    from sir_amd import train_ops
+    from sir_amd import ops, train_ops
     model.eval()
     loss_fn = _loss_fn(criterion)
     losses = []
@@ -144,6 +185,7 @@ def validate(model, val_loader, criterion, device, scaler=None):
             correct += (predicted == label).sum()
             total += label.size(0)
     counts = torch.tensor([int(correct.item()), total], dtype=torch.int64, device=device)
+    ops.check_status()                                # the host has just synchronised: surface a timed-out recurrence
     train_ops.all_reduce_sum_(counts)
     accuracy = counts[0].item() / max(counts[1].item(), 1)
     avg_loss = torch.stack(losses).mean().item() if losses else 0.0
@@ -171,9 +213,20 @@ def train(args, config):
 
     cache_dir = config.get("cache_dir", "data/cached_features")
     use_cache = config.get("use_feature_cache", True)
-    train_dataset = FSCIntentDataset(csv_path=args.train_csv, label_map_path=args.label_map, is_training=True,
-                                     augment_prob=config.get("augment_prob", 0.5), use_cache=use_cache,
-                                     cache_dir=cache_dir)
+    # Two YAML keys beyond the reference's, both off by default (= reference behaviour: cached features through
+    # DataLoader workers).  `fused_features: true` trains from RAW waveforms staged once in HBM, features computed on
+    # the GPU inside the step (BASELINE configs[2]); `waveform_augment: true` (implies fused_features) adds the
+    # time-shift / noise augmentation of scripts/augment.py inside the feature kernel (configs[4]).
+    wave_aug = bool(config.get("waveform_augment", False))
+    fused = bool(config.get("fused_features", False)) or wave_aug
+    train_store = None
+    if fused:
+        from sir_amd.waveform_store import WaveformStore
+        train_store = WaveformStore(args.train_csv, args.label_map, device,
+                                    sample_rate=int(config.get("sample_rate", 16000)))
+    train_dataset = train_store if fused else \
+        FSCIntentDataset(csv_path=args.train_csv, label_map_path=args.label_map, is_training=True,
+                         augment_prob=config.get("augment_prob", 0.5), use_cache=use_cache, cache_dir=cache_dir)
     val_dataset = FSCIntentDataset(csv_path=args.val_csv, label_map_path=args.label_map, is_training=False,
                                    use_cache=use_cache, cache_dir=cache_dir)
     if rank == 0:
@@ -181,11 +234,11 @@ def train(args, config):
 
     bs = config["batch_size"]                      # per-GPU batch; the global batch is bs * world
     nw = config.get("num_workers", 2)
-    train_sampler = train_ops.ShardSampler(len(train_dataset), rank, world, shuffle=True,
-                                           seed=int(config.get("seed", 0)))
+    seed = int(config.get("seed", 0))
+    train_sampler = train_ops.ShardSampler(len(train_dataset), rank, world, shuffle=True, seed=seed)
     val_sampler = train_ops.ShardSampler(len(val_dataset), rank, world, shuffle=False, pad=False)
-    train_loader = DataLoader(train_dataset, batch_size=bs, sampler=train_sampler, num_workers=nw,
-                              collate_fn=collate_fn, pin_memory=True)
+    train_loader = None if fused else DataLoader(train_dataset, batch_size=bs, sampler=train_sampler, num_workers=nw,
+                                                 collate_fn=collate_fn, pin_memory=True)
     val_loader = DataLoader(val_dataset, batch_size=bs * 2, sampler=val_sampler, num_workers=nw,
                             collate_fn=collate_fn, pin_memory=True)
 
@@ -204,8 +257,14 @@ def train(args, config):
     for epoch in range(epochs):
         if rank == 0:
             print(f"\nEpoch {epoch + 1}/{epochs}")
-        train_sampler.set_epoch(epoch)
-        train_loss = train_epoch(model, train_loader, optimizer, criterion, device, None)
+        if fused:
+            batches = train_store.epoch_batches(bs, rank, world, shuffle=True, seed=seed, epoch=epoch)
+            train_loss = train_epoch_waveforms(model, batches, optimizer, criterion, device,
+                                               t_pad=int(config.get("mel_spec_length", MAX_LENGTH)),
+                                               augment=make_waveform_augment(config, seed=seed + 977 * rank, epoch=epoch))
+        else:
+            train_sampler.set_epoch(epoch)
+            train_loss = train_epoch(model, train_loader, optimizer, criterion, device, None)
         val_loss, val_acc = validate(model, val_loader, criterion, device, None)
         if rank == 0:
             print(f"Train loss: {train_loss:.4f}, Val loss: {val_loss:.4f}, Val accuracy: {val_acc:.4f}")

@@ -23,6 +23,14 @@ OVERLAP_GRAD_EXCHANGE = os.environ.get("SIR_DDP_OVERLAP", "1") != "0"
 HAND_OVER_GRADS = os.environ.get("SIR_HAND_OVER_GRADS", "1") != "0"
 
 
+def dropout_seed(step_counter, rank=None):
+    """64-bit key of one step's inter-layer dropout mask: the process-local step counter and the data-parallel rank
+    (every rank must draw a DIFFERENT mask for its shard, as independent ``nn.GRU`` replicas would)."""
+    if rank is None:
+        rank = torch.distributed.get_rank() if world_size() > 1 else 0
+    return (step_counter * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03) % (1 << 64)
+
+
 def _has_grad_hooks(p):
     return bool(getattr(p, "_backward_hooks", None)) or bool(getattr(p, "_post_accumulate_grad_hooks", None))
 
@@ -96,7 +104,8 @@ class _TrainStep(torch.autograd.Function):
         w, keep = ops.cached_weights(mod)
         rm, rv = _bn_ptr_arrays(mod)
         logits = torch.empty((bsz, w.num_classes), dtype=torch.float32, device=x.device)
-        seed = next(_seed_counter) * 0x9E3779B97F4A7C15 % (1 << 64)
+        seed = dropout_seed(next(_seed_counter))
+        mod._sir_last_dropout = (seed, float(dropout_p))      # lets tests rebuild the mask (tests/dropout_host.py)
         momentum = float(mod.bn1.momentum if mod.bn1.momentum is not None else 0.1)
         rc = lib.sir_model_train_fwd(h, C.byref(w), rm, rv, x.data_ptr(), bsz, t, momentum, float(dropout_p), seed,
                                      logits.data_ptr(), ws.data_ptr(), ws.numel(), _native.current_stream_ptr())
@@ -129,21 +138,7 @@ class _TrainStep(torch.autograd.Function):
                                               _native.current_stream_ptr())
             _native.check(rc, "sir_model_train_bwd_part")
 
-        world = world_size()
-        if world > 1 and OVERLAP_GRAD_EXCHANGE:
-            # data parallel: the GRU / attention / fc gradients (96 % of the 13 MB) are final after the first half of the
-            # backward; their all-reduce runs beside the conv backward, the small conv / BN bucket follows
-            import torch.distributed as dist
-            run(_native.BWD_HEAD_GRU)
-            tail = grads.flat[grads.n_cnn:]
-            work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True)
-            run(_native.BWD_CNN)
-            dist.all_reduce(grads.flat[:grads.n_cnn], op=dist.ReduceOp.SUM)
-            work.wait()
-            grads.flat.mul_(1.0 / world)
-        else:
-            run(_native.BWD_ALL)
-            all_reduce_mean_(grads.flat)            # the one exchange step of data-parallel training
+        _exchange_and_scale(grads, run)
         need = ctx.needs_input_grad[3:]
         if HAND_OVER_GRADS and all(p.grad is None and not _has_grad_hooks(p) for p in params):
             # zero_grad(set_to_none=True) (train.py:90): the views of the flat buffer BECOME the .grad tensors; returning
@@ -153,6 +148,44 @@ class _TrainStep(torch.autograd.Function):
                     p.grad = v
             return (None, None, None) + (None,) * len(params)
         return (None, None, None) + tuple(v if n else None for v, n in zip(grads.views, need))
+
+
+def _exchange_and_scale(grads, run):
+    """The per-step gradient exchange around the two halves of the backward (``run(part)`` launches one half, or
+    nothing for a rank that has no batch)."""
+    world = world_size()
+    if world > 1 and OVERLAP_GRAD_EXCHANGE:
+        # data parallel: the GRU / attention / fc gradients (96 % of the 13 MB) are final after the first half of the
+        # backward; their all-reduce runs beside the conv backward, the small conv / BN bucket follows
+        import torch.distributed as dist
+        run(_native.BWD_HEAD_GRU)
+        tail = grads.flat[grads.n_cnn:]
+        work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True)
+        run(_native.BWD_CNN)
+        dist.all_reduce(grads.flat[:grads.n_cnn], op=dist.ReduceOp.SUM)
+        work.wait()
+        grads.flat.mul_(1.0 / world)
+    else:
+        run(_native.BWD_ALL)
+        all_reduce_mean_(grads.flat)            # the one exchange step of data-parallel training
+
+
+def zero_contribution_step(mod):
+    """Data-parallel step of a rank whose batch is empty (``collate_fn`` dropped every item, train.py:67-68 / :82-83):
+    the other ranks are inside the gradient all-reduce, so this rank joins the same collectives with a zero gradient
+    and ends up with the same averaged ``.grad`` as they do (the caller then runs ``optimizer.step()`` like everyone
+    else, keeping the replicas identical).  Without it the job would hang on the mismatched collective."""
+    st = _train_state(mod)
+    grads = st["grads"]
+    params = param_list(mod)
+    for p, v in zip(params, grads.views):
+        if p.grad is not None and p.grad.data_ptr() == v.data_ptr():
+            p.grad = None
+    grads.flat.zero_()
+    _exchange_and_scale(grads, lambda part: None)
+    for p, v in zip(params, grads.views):
+        if p.requires_grad:
+            p.grad = v
 
 
 def forward_train(mod, x):

@@ -1,0 +1,105 @@
+"""A whole dataset split resident in HBM as raw waveforms (BASELINE configs[2] / [4]: "fused HIP feature-extract +
+forward/backward + Adam", "on-the-fly augmentation fused into the HIP feature kernel").
+
+The reference keeps *features* in host RAM and feeds them through DataLoader workers (scripts/dataset.py:44-56,
+scripts/train.py:199-219); raw audio is touched once, by the serial precompute loop.  With 288 GB of HBM per MI355X the
+raw training split itself fits on the device many times over (Fluent Speech Commands: 23 k clips x <= 5 s x 2 B = 3.7 GB
+as PCM16), so the fused training route stages each rank's shard ONCE -- decode on the host, mono mix-down / resampling on
+the GPU (``sir_mix_to_mono`` / ``sir_resample``), stored as one ``[N, Lmax]`` tensor -- and every step then gathers its
+batch with one device-side ``index_select``: no per-step PCIe traffic, no worker processes, and the waveform
+augmentation (scripts/augment.py) has real samples to work on.  PCM16 mono clips already at 16 kHz stay int16 (lossless;
+the feature kernel dequantises with torchaudio.load's 1/32768); anything that went through the mixer or the resampler is
+kept as float32.
+"""
+import json
+import logging
+import os
+
+import pandas as pd
+import torch
+
+from . import _native
+from .dist_utils import ShardSampler
+
+logger = logging.getLogger(__name__)
+
+
+class WaveformStore:
+    """``len(store)`` clips of one CSV split on ``device``; ``epoch_batches`` yields ``(wave [B, L], lengths int32 [B],
+    labels int64 [B], host_lengths list[int])`` -- device tensors plus a host copy of the lengths -- in ``ShardSampler``
+    order (rank r takes i = r mod world of the shuffled epoch).
+
+    Error convention of the reference (dataset.py:84, :121-123, :156-158): an unknown label maps to id 0; a clip that
+    cannot be read keeps its label and an empty waveform (length 0), for which the feature kernel emits the all-zero
+    spectrogram the reference substitutes."""
+
+    def __init__(self, csv_path, label_map_path, device, max_duration=5.0, sample_rate=16000, stage_batch=512):
+        _native.require_hip()
+        from .scripts.precompute_features import AudioFeatureExtractor
+        self.device = torch.device(device)
+        self.sample_rate = sample_rate
+        data = pd.read_csv(csv_path)
+        with open(label_map_path, "r") as f:
+            label_map = json.load(f)
+        paths = data["path"].tolist()
+        self.labels = torch.tensor([label_map.get(lab, 0) for lab in data["label"].tolist()], dtype=torch.int64,
+                                   device=self.device)
+        n = len(paths)
+        max_samples = int(max_duration * sample_rate)
+        ex = AudioFeatureExtractor(sample_rate)
+        staged = []                                   # (indices, wave [k, L] device, lens [k] device)
+        all_int16 = True
+        failed = 0
+        for start in range(0, n, stage_batch):
+            groups = {}
+            for i in range(start, min(start + stage_batch, n)):
+                try:
+                    item = ex._load(paths[i], max_duration)
+                except Exception as e:
+                    logger.error(f"Error processing {paths[i]}: {str(e)}")
+                    item = None
+                if item is None:
+                    failed += 1
+                    continue
+                d, ch, sr = item
+                groups.setdefault((ch, sr, d.dtype), []).append((i, d))
+            for (ch, sr, _), items in groups.items():
+                wave, lens = ex.waveforms_of_group([d for _, d in items], ch, sr, max_duration)
+                all_int16 = all_int16 and wave.dtype == torch.int16
+                staged.append((torch.tensor([i for i, _ in items], dtype=torch.int64, device=self.device), wave, lens))
+        lmax = max([int(w.shape[1]) for _, w, _ in staged] + [1])
+        lmax = min((lmax + 7) // 8 * 8, (max_samples + 7) // 8 * 8)          # rows stay 16-byte aligned
+        dtype = torch.int16 if all_int16 else torch.float32
+        self.wave = torch.zeros((n, lmax), dtype=dtype, device=self.device)
+        self.lengths = torch.zeros((n,), dtype=torch.int32, device=self.device)
+        self.host_lengths = None                      # filled below: lets the augmentation draw without a device sync
+        for idx, wave, lens in staged:
+            if wave.dtype != dtype:                    # int16 group inside a float32 store: torchaudio.load's normalisation
+                wave = wave.to(torch.float32) / 32768.0
+            w = min(int(wave.shape[1]), lmax)
+            self.wave[idx, :w] = wave[:, :w]
+            self.lengths[idx] = lens
+        self.host_lengths = self.lengths.cpu()
+        if failed:
+            logger.error(f"{failed} of {n} clips could not be read (empty waveforms -> zero spectrograms)")
+        logger.info(f"staged {n} clips as {dtype} [{n}, {lmax}] on {self.device} "
+                    f"({self.wave.numel() * self.wave.element_size() / 2 ** 20:.1f} MiB)")
+
+    def __len__(self):
+        return int(self.wave.shape[0])
+
+    def epoch_batches(self, batch_size, rank=0, world=1, shuffle=True, seed=0, epoch=0):
+        """One epoch of this rank's shard (the host only handles indices)."""
+        sampler = ShardSampler(len(self), rank, world, shuffle=shuffle, seed=seed)
+        sampler.set_epoch(epoch)
+        host_order = torch.tensor(list(sampler), dtype=torch.int64)
+        order = host_order.to(self.device)
+        for start in range(0, int(order.numel()), batch_size):
+            idx = order[start:start + batch_size]
+            host_lens = self.host_lengths[host_order[start:start + batch_size]].tolist()
+            yield self.wave.index_select(0, idx), self.lengths.index_select(0, idx), self.labels.index_select(0, idx), host_lens
+
+
+def frames_of(lengths, hop=512):
+    """Un-padded frame count per clip (1 + L // hop), host list."""
+    return [1 + int(v) // hop for v in lengths]

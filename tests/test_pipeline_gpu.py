@@ -146,3 +146,97 @@ def test_two_rank_gradient_mean(tmp_path):
     for k in g0:
         mean = 0.5 * (shard_grads[0][k] + shard_grads[1][k])
         assert (g0[k] - mean).abs().max() <= 1e-6 * max(1.0, mean.abs().max().item()), k
+
+
+def _write_splits(tmp_path, rows):
+    csvs = {}
+    for split, sl in (("train", slice(0, 16)), ("valid", slice(16, 20)), ("test", slice(20, 24))):
+        p = tmp_path / f"{split}_data.csv"
+        pd.DataFrame(rows[sl]).to_csv(p, index=False)
+        csvs[split] = str(p)
+    lm = tmp_path / "label_map.json"
+    lm.write_text(json.dumps({l: i for i, l in enumerate(sorted(LABELS))}))
+    return csvs, str(lm)
+
+
+def _oracle_features(path):
+    wave, sr = wav_io.read_wav(path)
+    return features_ref.extract_features_f32(resample_ref.resample(wave.mean(0, keepdim=True), sr, 16000)[0])
+
+
+def test_dataset_without_cache_serves_real_features_to_workers(tmp_path):
+    """with use_cache=False (or a missing cache file) and DataLoader workers the reference computes the
+    features in the worker (dataset.py:97-98, :117-158); the drop-in must not train on zeros.  Every uncached clip is
+    extracted on the GPU by the constructor (main process); the workers then serve oracle-matching features, and only the
+    two clips that genuinely fail (too short, missing file) are the reference's zero spectrogram."""
+    from torch.utils.data import DataLoader
+    from sir_amd.scripts import train as tr
+    from sir_amd.scripts.dataset import FSCIntentDataset
+    rows = _make_corpus(str(tmp_path / "wav"))
+    csvs, lm = _write_splits(tmp_path, rows)
+    ds = FSCIntentDataset(csvs["train"], lm, is_training=False, use_cache=False, cache_dir=str(tmp_path / "nocache"))
+    assert ds.missing_paths() == []                                  # everything was extracted up front
+    loader = DataLoader(ds, batch_size=4, shuffle=False, num_workers=2, collate_fn=tr.collate_fn)
+    got = torch.cat([mel for mel, _ in loader])
+    assert got.shape == (16, 64, 200)
+    for i in range(16):
+        if i in (5, 9):
+            assert (got[i] == 0).all(), i
+            continue
+        ref = features_ref.pad_or_trim(_oracle_features(rows[i]["path"]))
+        assert ((got[i] - ref).abs() <= 1e-4 * ref.abs().clamp(min=1.0)).all(), i
+        assert got[i].abs().max() > 0.1
+    # a partial cache: only the misses are extracted, cached entries are served as they are
+    from sir_amd.scripts import precompute_features as pf
+    cache_dir = str(tmp_path / "cache")
+    cache = pf.precompute_dataset_features(csvs["train"], cache_dir)
+    full = torch.load(cache)
+    keep = {k: v for j, (k, v) in enumerate(full.items()) if j % 2 == 0}
+    torch.save(keep, cache)
+    ds2 = FSCIntentDataset(csvs["train"], lm, is_training=False, use_cache=True, cache_dir=cache_dir)
+    assert set(ds2.in_memory_cache) == {r["path"] for r in rows[:16]} - set(keep)
+    for i in (0, 1, 2, 4):
+        assert torch.equal(ds2[i][0], got[i]), i
+
+
+def test_train_from_waveforms_with_fused_augmentation(tmp_path):
+    """BASELINE configs[2] / [4] from the reference's entry point: `fused_features` + `waveform_augment` make train() stage
+    the raw split in HBM (WaveformStore) and run train_epoch_waveforms with shift / noise / SpecAugment drawn per batch."""
+    from sir_amd.featurizer import get_featurizer
+    from sir_amd.scripts import train as tr
+    from sir_amd.waveform_store import WaveformStore
+    rows = _make_corpus(str(tmp_path / "wav"))
+    csvs, lm = _write_splits(tmp_path, rows)
+    store = WaveformStore(csvs["train"], lm, "cuda")
+    assert len(store) == 16 and store.wave.dtype == torch.float32      # the corpus has a stereo and a 22.05 kHz clip
+    host_len = store.host_lengths.tolist()
+    assert host_len[9] == 0 and host_len[5] == 300                      # missing file / short clip keep their rows
+    fz = get_featurizer()
+    feats = fz(store.wave, store.lengths, t_pad=200).cpu()
+    for i in range(16):
+        if i in (5, 9):
+            assert (feats[i] == 0).all(), i                             # the reference's zero spectrogram
+            continue
+        ref = features_ref.pad_or_trim(_oracle_features(rows[i]["path"]))
+        assert ((feats[i] - ref).abs() <= 1e-4 * ref.abs().clamp(min=1.0)).all(), i
+    seen = []
+    for wave, lens, labels, hl in store.epoch_batches(6, rank=1, world=2, shuffle=True, seed=3, epoch=1):
+        assert wave.shape[0] == lens.shape[0] == labels.shape[0] == len(hl) and lens.cpu().tolist() == hl
+        seen += hl
+    assert len(seen) == 8
+    # a PCM16 / 16 kHz / mono-only split stays int16 (lossless, half the bytes)
+    mono = [r for i, r in enumerate(rows) if i not in (3, 7)][:8]
+    pd.DataFrame(mono).to_csv(tmp_path / "mono.csv", index=False)
+    assert WaveformStore(str(tmp_path / "mono.csv"), lm, "cuda").wave.dtype == torch.int16
+
+    cfg = {"batch_size": 8, "num_workers": 0, "num_labels": 31, "lr": 1e-3, "weight_decay": 1e-4, "epochs": 2,
+           "early_stop_patience": 5, "augment_prob": 0.7, "use_feature_cache": False, "cache_dir": str(tmp_path / "nocache"),
+           "save_path": str(tmp_path / "ckpt"), "fused_features": True, "waveform_augment": True, "seed": 1}
+    args = types.SimpleNamespace(train_csv=csvs["train"], val_csv=csvs["valid"], label_map=lm)
+    best = tr.train(args, cfg)
+    assert 0.0 <= best <= 1.0
+    aug = tr.make_waveform_augment(cfg, seed=1, epoch=0)
+    kw = aug(0, 4, [48000, 30000, 16000, 700])
+    assert set(kw) == {"shift", "noise_sigma", "noise_seed", "time_mask", "freq_mask"} and kw["shift"].shape == (4,)
+    assert (kw["shift"].abs() <= torch.tensor([4800, 3000, 1600, 70])).all() and (kw["noise_sigma"] <= 0.01).all()
+    assert set(tr.make_waveform_augment({"fused_features": True, "augment_prob": 0.0}, seed=1)(0, 2, [48000, 48000])) == set()
