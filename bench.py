@@ -320,8 +320,13 @@ def main():
     # SIR_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box): every rank uses cuda:0 and the gloo backend, to exercise
     # the multi-rank code path; real runs use one GPU per rank and RCCL ("nccl")
     share_gpu = os.environ.get("SIR_BENCH_SHARE_GPU", "0") == "1"
+    batch = BATCH
     if share_gpu:
         local_rank = 0
+        # N ranks on ONE GPU is a rehearsal of the code path, not a measurement: the GRU recurrences are cluster kernels
+        # whose workgroups own a whole CU each (128 / 256 of them per launch at batch 256), and launches of SEVERAL
+        # processes cannot be chained against each other, so the ranks get a batch whose clusters all fit side by side
+        batch = max(16, BATCH // (2 * world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -361,8 +366,8 @@ def main():
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     fz = get_featurizer()
-    pool = [device_clips(BATCH, CLIP_LEN, 1234 + 1000 * rank + i, dev) for i in range(N_POOL)]
-    lengths = torch.full((BATCH,), CLIP_LEN, dtype=torch.int32, device=dev)
+    pool = [device_clips(batch, CLIP_LEN, 1234 + 1000 * rank + i, dev) for i in range(N_POOL)]
+    lengths = torch.full((batch,), CLIP_LEN, dtype=torch.int32, device=dev)
     preds = [None]
     # batch pipelining (sir_amd/pipeline.py): consecutive batches alternate over `--streams` HIP streams, each with
     # its own feature buffer, feature workspace and model workspace (weights shared), so that the latency-bound
@@ -370,7 +375,7 @@ def main():
     from sir_amd.pipeline import BatchPipeline
     ns = max(1, args.streams)
     pipe = BatchPipeline(model, n_streams=ns)
-    feats = [torch.empty(BATCH, 64, T_PAD, device=dev) for _ in range(ns)]
+    feats = [torch.empty(batch, 64, T_PAD, device=dev) for _ in range(ns)]
 
     def step(i):
         k = pipe.slot(i)
@@ -449,7 +454,7 @@ def main():
         t1 = timed_regions(step1, args.steps, args.repeats)
         el1 = statistics.median(t1)
         iso_ms, iso_cnt = collect()
-        single = {"value": round(BATCH * world * args.steps / el1, 1), "ms_per_step": round(el1 / args.steps * 1e3, 4),
+        single = {"value": round(batch * world * args.steps / el1, 1), "ms_per_step": round(el1 / args.steps * 1e3, 4),
                   "timed_regions": region_stats(t1, args.steps),
                   "dominant_avg_launch_ms": round(iso_ms[dominant], 5), "dominant_launches": iso_cnt[dominant]}
     lib.sir_profile_enable(fz.handle, 0, -1)
@@ -470,8 +475,8 @@ def main():
         import random
         model.train()
         opt = FusedAdam(model.parameters(), lr=5e-5, weight_decay=1e-4)
-        labels = torch.randint(0, NUM_CLASSES, (BATCH,), device=dev)
-        host_lengths = [CLIP_LEN] * BATCH
+        labels = torch.randint(0, NUM_CLASSES, (batch,), device=dev)
+        host_lengths = [CLIP_LEN] * batch
         rng = random.Random(4321 + rank)
 
         def tstep(i, augment=False):
@@ -505,16 +510,16 @@ def main():
             lib.sir_profile_enable(fz.handle, 0, -1)
             t_el = statistics.median(tt)
             ms = t_el / args.train_steps * 1e3
-            step_tf = TRAIN_FLOPS_PER_UTT * BATCH / (ms * 1e-3) / 1e12
-            info = {"value": round(BATCH * world * args.train_steps / t_el, 1), "unit": "utterances/s",
+            step_tf = TRAIN_FLOPS_PER_UTT * batch / (ms * 1e-3) / 1e12
+            info = {"value": round(batch * world * args.train_steps / t_el, 1), "unit": "utterances/s",
                     "ms_per_step": round(ms, 4), "steps": args.train_steps, "timed_regions": region_stats(tt, args.train_steps),
                     "workload": "waveform batch 256/GPU -> HIP features" +
                                 (" with fused time-shift + noise + SpecAugment masks" if augment else "") +
                                 " -> forward/backward (dropout 0.5, batch-stat BN) -> Adam(lr 5e-5, wd 1e-4)" +
                                 (", RCCL all-reduce of 13 MB grads in two overlapped buckets" if world > 1 else ""),
                     "model_flops_per_utt_fwd_bwd": TRAIN_FLOPS_PER_UTT,
-                    "roofline": dict(mfma_roofline(tdom, td_ms[tdom], td_cnt[tdom]),
-                                     whole_step={"flops_per_step": TRAIN_FLOPS_PER_UTT * BATCH, "achieved": round(step_tf, 2),
+                    "roofline": dict(mfma_roofline(tdom, td_ms[tdom], td_cnt[tdom], batch),
+                                     whole_step={"flops_per_step": TRAIN_FLOPS_PER_UTT * batch, "achieved": round(step_tf, 2),
                                                  "peak": round(PEAK_BF16X6_TFLOPS, 1), "unit": "TFLOP/s",
                                                  "frac": round(step_tf / PEAK_BF16X6_TFLOPS, 4),
                                                  "note": "1.2019 GFLOP/utt (fwd + dgrad + wgrad convention) x 256 / per-GPU step time"}),
@@ -530,17 +535,17 @@ def main():
     ops.check_status()                                          # a timed-out GRU recurrence would invalidate every figure
 
     if rank == 0:
-        total_utts = BATCH * world * args.steps
+        total_utts = batch * world * args.steps
         value = total_utts / elapsed
         d_ms = dom_ms[dominant]
         if dominant in FLOPS_PER_UTT:
-            roofline = mfma_roofline(dominant, d_ms, dom_cnt[dominant])
+            roofline = mfma_roofline(dominant, d_ms, dom_cnt[dominant], batch)
             if single is not None:
                 # with several streams the kernel's launches in the pipelined region share the CUs with the other stream's
                 # kernels (its "duration" then includes co-scheduling); the roofline of the KERNEL is taken from the
                 # single-stream timed leg of this same run (K steps, HIP events on the launch stream), and the pipelined
                 # figures are kept beside it
-                iso = mfma_roofline(dominant, single["dominant_avg_launch_ms"], single["dominant_launches"])
+                iso = mfma_roofline(dominant, single["dominant_avg_launch_ms"], single["dominant_launches"], batch)
                 iso["pipelined"] = {"streams": ns, "avg_launch_ms": roofline["avg_launch_ms"], "achieved": roofline["achieved"],
                                     "frac": roofline["frac"],
                                     "note": "same kernel inside the multi-stream timed region: it shares the GPU with the other "
@@ -548,18 +553,19 @@ def main():
                 iso["measured_in"] = "single-stream timed leg of this run (same K steps, one HIP stream)"
                 roofline = iso
         else:
-            achieved = FEATURE_BYTES_PER_UTT * BATCH / (d_ms * 1e-3) / 1e9
+            achieved = FEATURE_BYTES_PER_UTT * batch / (d_ms * 1e-3) / 1e9
             roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None,
                         "avg_launch_ms": round(d_ms, 5), "launches": dom_cnt[dominant],
-                        "bytes_per_launch": FEATURE_BYTES_PER_UTT * BATCH}
+                        "bytes_per_launch": FEATURE_BYTES_PER_UTT * batch}
         feat_ms = kernel_ms.get("feat_frames", 0.0) + kernel_ms.get("feat_normalise", 0.0)
         gru = {}
         for k, algo in GRU_ALGO_BYTES.items():
+            algo = algo * batch // BATCH
             tr, src = pmc_traffic(k)
             gru[k] = {"avg_ms": round(kernel_ms.get(k, 0.0), 5), "algorithmic_bytes_per_launch": algo, "traffic": tr,
                       "traffic_source": src, "traffic_over_algorithmic": round(tr / algo, 2) if tr else None,
-                      "achieved_TFLOPs": round(FLOPS_PER_UTT[k] * BATCH / (kernel_ms[k] * 1e-3) / 1e12, 2) if kernel_ms.get(k) else None}
+                      "achieved_TFLOPs": round(FLOPS_PER_UTT[k] * batch / (kernel_ms[k] * 1e-3) / 1e12, 2) if kernel_ms.get(k) else None}
         out = {
             "metric": "utterances/sec (16 kHz, 3 s clips), inference: HIP STFT+mel+CNN/BiGRU forward + argmax",
             "value": round(value, 1), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
@@ -568,18 +574,19 @@ def main():
             "timed_regions": region_stats(times, args.steps),
             "config": {"workload": "1xMI355X inference (BASELINE configs[1]): batch=256 synthetic 16 kHz / 3 s clips "
                                    "resident in HBM -> 64-mel log-mel [64,200] -> CNNAudioGRU(31) forward -> argmax",
-                       "batch_per_gpu": BATCH, "clip_samples": CLIP_LEN, "n_mels": 64, "frames": T_PAD,
+                       "batch_per_gpu": batch, "clip_samples": CLIP_LEN, "n_mels": 64, "frames": T_PAD,
                        "num_classes": NUM_CLASSES, "parallelism": f"utterance-sharded x{world}, no data-path collective",
                        "streams_per_gpu": ns,
+                       "share_gpu_rehearsal": share_gpu,
                        "arithmetic": "fp32 accuracy end to end: contractions as bf16x6 (three-way bf16 split of both operands, six "
                                      "v_mfma_f32_32x32x16_bf16 products, f32 accumulation), everything else fp32 VALU"},
             "dist": dist_info,
             "roofline": roofline,
             "kernels_avg_ms": {k: round(kernel_ms[k], 5) for k in infer_names},
             "features_stage": {"bound": "hbm", "avg_ms": round(feat_ms, 5),
-                               "achieved_GBs": round(FEATURE_BYTES_PER_UTT * BATCH / (feat_ms * 1e-3) / 1e9, 1) if feat_ms else None,
-                               "peak_GBs": PEAK_HBM_GBS, "frac": round(FEATURE_BYTES_PER_UTT * BATCH / (feat_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if feat_ms else None,
-                               "bytes_per_launch": FEATURE_BYTES_PER_UTT * BATCH},
+                               "achieved_GBs": round(FEATURE_BYTES_PER_UTT * batch / (feat_ms * 1e-3) / 1e9, 1) if feat_ms else None,
+                               "peak_GBs": PEAK_HBM_GBS, "frac": round(FEATURE_BYTES_PER_UTT * batch / (feat_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if feat_ms else None,
+                               "bytes_per_launch": FEATURE_BYTES_PER_UTT * batch},
             "gru_recurrence": gru,
         }
         if single is not None:

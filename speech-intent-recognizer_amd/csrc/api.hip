@@ -49,6 +49,7 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     for (auto& e : h->prep) { e.ws = nullptr; e.version = 0; e.key = -1; }
     h->tw512 = nullptr; h->tw1024 = nullptr; h->window = nullptr; h->melw = nullptr; h->mel_start = nullptr;
     h->status = nullptr;
+    h->cluster_done = nullptr; h->cluster_stream = nullptr; h->cluster_pending = false;
     h->cfg = *cfg;
     h->cfg.window = nullptr;
     h->cfg.mel_fb = nullptr;
@@ -101,6 +102,7 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     if (rc == SIR_OK) rc = upload(&h->melw, melw);
     if (rc == SIR_OK) rc = upload(&h->mel_start, start);
     if (rc == SIR_OK) rc = upload(&h->status, std::vector<unsigned int>(64, 0u));
+    if (rc == SIR_OK) rc = sir_check_hip(hipEventCreateWithFlags(&h->cluster_done, hipEventDisableTiming), "hipEventCreate");
     if (rc != SIR_OK) { sir_destroy(h); return rc; }
     *out = h;
     return SIR_OK;
@@ -110,6 +112,7 @@ extern "C" int sir_destroy(sir_handle* h) {
     if (!h) return SIR_OK;
     (void)hipFree(h->tw512); (void)hipFree(h->tw1024); (void)hipFree(h->window);
     (void)hipFree(h->melw); (void)hipFree(h->mel_start); (void)hipFree(h->status);
+    if (h->cluster_done) (void)hipEventDestroy(h->cluster_done);
     for (auto& t : h->resample_tables) { (void)hipFree(t.taps); (void)hipFree(t.first); }
     for (auto& r : h->prof_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : h->prof_free) (void)hipEventDestroy(e);

@@ -281,6 +281,7 @@ if (occ)
     hipLaunchKernelGGL((gemm_nt_bias_kernel<32, false>), ggrid, dim3(256), 0, st, x0, 1024, w->gru_w_ih[0], w->gru_w_ih[1], 1024,
                        w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024); }
     { SirProfScope prof(h, SIR_K_GRU0, st);
+    if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
     if (gru_variant == 2) {
         const int rc = sir_launch_gru_quad(st, false, gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S, nullptr, gxb, h->status,
                                            fuse_y0 ? xs : nullptr, wht, (unsigned char*)wht + (size_t)768 * 256 * 6);
@@ -290,7 +291,8 @@ if (occ)
         if (rc != SIR_OK) return rc;
     } else
     hipLaunchKernelGGL(gru_recurrence_kernel<false>, rgrid, dim3(GRU_THREADS), GRU_LDS_BYTES, st, gi, wht, w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S,
-                       (float*)nullptr); }
+                       (float*)nullptr);
+    if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP; }
     { SirProfScope prof(h, SIR_K_GEMM_IH1, st);
     if (gemm_variant == 2) {
         if (!fuse_y0) hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, (const float*)y0, 512, xs, (size_t)M, 512);
@@ -300,6 +302,7 @@ if (occ)
     hipLaunchKernelGGL((gemm_nt_bias_kernel<32, true>), ggrid, dim3(256), 0, st, y0, 512, w->gru_w_ih[2], w->gru_w_ih[3], 512,
                        w->gru_b_ih[2], w->gru_b_ih[3], gi, 1536, M, 768, 512); }
     { SirProfScope prof(h, SIR_K_GRU1, st);
+    if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
     if (gru_variant == 2) {
         const int rc = sir_launch_gru_quad(st, false, gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], y1, B, S, nullptr, gxb, h->status,
                                            nullptr, (unsigned char*)wht + (size_t)2 * 768 * 256 * 6, (unsigned char*)wht + (size_t)3 * 768 * 256 * 6);
@@ -309,7 +312,8 @@ if (occ)
         if (rc != SIR_OK) return rc;
     } else
     hipLaunchKernelGGL(gru_recurrence_kernel<false>, rgrid, dim3(GRU_THREADS), GRU_LDS_BYTES, st, gi, wht + (size_t)2 * 768 * 256, w->gru_b_hh[2],
-                       w->gru_b_hh[3], y1, B, S, (float*)nullptr); }
+                       w->gru_b_hh[3], y1, B, S, (float*)nullptr);
+    if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP; }
     SIR_KCHECK();
 
     // ---- attention pooling + classifier head ------------------------------------------------

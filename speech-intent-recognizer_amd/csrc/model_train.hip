@@ -313,9 +313,11 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     SIR_HIP_TRY(launch_gemm_nt_bf16x6(st, sir_gemm_bf16x6_gen(), (const unsigned short*)p.xs, (const unsigned short*)p.wsl0,
                        (const unsigned short*)(p.wsl0 + (size_t)3 * 768 * 1024), w->gru_b_ih[0], w->gru_b_ih[1], p.gi, 1536, M, 768, 1024)); }
     { SirProfScope prof(h, SIR_K_T_GRU0, st);
+    if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
     rc = sir_gru_variant() == 2
              ? sir_launch_gru_quad(st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0, p.gxb, h->status)
-             : sir_launch_gru_pair(st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0, p.gxb, p.gfl, h->status); }
+             : sir_launch_gru_pair(st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0, p.gxb, p.gfl, h->status);
+    if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP; }
     if (rc != SIR_OK) return rc;
     const float* y0in = p.y0;
     if (dropout_p > 0.0f) {
@@ -329,9 +331,11 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     SIR_HIP_TRY(launch_gemm_nt_bf16x6(st, sir_gemm_bf16x6_gen(), (const unsigned short*)p.xs, (const unsigned short*)p.wsl1,
                        (const unsigned short*)(p.wsl1 + (size_t)3 * 768 * 512), w->gru_b_ih[2], w->gru_b_ih[3], p.gi, 1536, M, 768, 512)); }
     { SirProfScope prof(h, SIR_K_T_GRU1, st);
+    if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
     rc = sir_gru_variant() == 2
              ? sir_launch_gru_quad(st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1, p.gxb, h->status)
-             : sir_launch_gru_pair(st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1, p.gxb, p.gfl, h->status); }
+             : sir_launch_gru_pair(st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1, p.gxb, p.gfl, h->status);
+    if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP; }
     if (rc != SIR_OK) return rc;
     SirProfScope prof_head(h, SIR_K_T_HEAD, st);
     hipLaunchKernelGGL(attention_pool_kernel, dim3(B), dim3(256), 0, st, p.y1, w->attn_w, w->attn_b, p.ctx, S, w->fc_w,
@@ -421,9 +425,11 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
 static const int gru_bwd_variant = getenv("SIR_GRU_BWD_VARIANT") ? atoi(getenv("SIR_GRU_BWD_VARIANT")) : 1;
         { SirProfScope prof(h, layer ? SIR_K_B_GRU1 : SIR_K_B_GRU0, st);
         if (gru_bwd_variant == 1) {
+            if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
             rc = sir_launch_gru_bwd_pair(st, dy, gates, yout, w->gru_w_hh[2 * layer], w->gru_w_hh[2 * layer + 1], p.dgi, p.dgh, bsum_i, bsum_h,
                                          B, S, p.gxb, h->status);
             if (rc != SIR_OK) return rc;
+            if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP;
         } else
         hipLaunchKernelGGL(gru_bwd_kernel, dim3((B + GRU_BBW - 1) / GRU_BBW, 2), dim3(1024), 0, st, dy, gates, yout, (const float*)(p.wr4 + (size_t)2 * layer * 768 * 256),
                            p.dgi, p.dgh, bsum_i, bsum_h, B, S);

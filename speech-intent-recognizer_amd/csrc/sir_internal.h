@@ -60,7 +60,28 @@ struct sir_handle {
     // device word set to 1 by a GRU recurrence kernel whose inter-workgroup exchange timed out (its results are then
     // invalid); zeroed at creation, read and cleared by sir_check_status / sir_profile_collect
     unsigned int* status;
+    // Cluster kernels (the GRU recurrences) need every workgroup of a cluster resident at once; dispatch order
+    // guarantees that within ONE launch, but two such launches on different streams interleave their dispatch and, once
+    // their workgroups outnumber the CUs, can fill the chip with partial clusters that wait for each other for ever (seen
+    // with 2 processes x 2 streams on one GPU: spin time-outs).  Launches of cluster kernels issued through this handle are
+    // therefore chained: one on another stream first waits for the previous one's completion event.
+    hipEvent_t cluster_done;
+    hipStream_t cluster_stream;
+    bool cluster_pending;
 };
+
+// bracket of a cluster-kernel launch (see sir_handle::cluster_done)
+static inline int sir_cluster_enter(sir_handle* h, hipStream_t st) {
+    if (h->cluster_pending && h->cluster_stream != st)
+        if (hipStreamWaitEvent(st, h->cluster_done, 0) != hipSuccess) return SIR_EHIP;
+    return SIR_OK;
+}
+static inline int sir_cluster_leave(sir_handle* h, hipStream_t st) {
+    if (hipEventRecord(h->cluster_done, st) != hipSuccess) return SIR_EHIP;
+    h->cluster_stream = st;
+    h->cluster_pending = true;
+    return SIR_OK;
+}
 
 void sir_set_error(const char* fmt, ...);
 int sir_check_hip(hipError_t e, const char* what);
