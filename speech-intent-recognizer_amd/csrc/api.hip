@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -47,7 +48,7 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     h->prof_mode = 0; h->prof_only = -1;
     h->weights_version = 0; h->prep_next = 0;
     for (auto& e : h->prep) { e.ws = nullptr; e.version = 0; e.key = -1; }
-    h->tw512 = nullptr; h->tw1024 = nullptr; h->window = nullptr; h->melw = nullptr; h->mel_start = nullptr;
+    h->tw512 = nullptr; h->tw1024 = nullptr; h->window = nullptr; h->melw = nullptr; h->mel_desc = nullptr;
     h->status = nullptr;
     h->cluster_done = nullptr; h->cluster_stream = nullptr; h->cluster_pending = false;
     h->cfg = *cfg;
@@ -82,25 +83,43 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
             }
         }
     }
+    // compact per-filter tap lists; slots = filters sorted by tap count (feat_utt_kernel: a wave handles four
+    // consecutive slots, i.e. four equally long filters)
     std::vector<int> start(SIR_MAX_MELS, 0), count(SIR_MAX_MELS, 0);
-    int max_taps = 1;
     for (int j = 0; j < nm; ++j) {
         int lo = -1, hi = -1;
         for (int k = 0; k < SIR_NFREQ; ++k)
             if (fb[(size_t)k * nm + j] != 0.0f) { if (lo < 0) lo = k; hi = k; }
         if (lo >= 0) { start[j] = lo; count[j] = hi - lo + 1; }
-        if (count[j] > max_taps) max_taps = count[j];
     }
-    std::vector<float> melw((size_t)max_taps * SIR_MAX_MELS, 0.0f);
-    for (int j = 0; j < nm; ++j)
-        for (int i = 0; i < count[j]; ++i) melw[(size_t)i * SIR_MAX_MELS + j] = fb[(size_t)(start[j] + i) * nm + j];
-    h->max_taps = max_taps;
+    std::vector<int> order(SIR_MAX_MELS);
+    for (int j = 0; j < SIR_MAX_MELS; ++j) order[j] = j;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        const int ca = a < nm ? count[a] : -1, cb = b < nm ? count[b] : -1;      // unused slots first
+        return ca < cb;
+    });
+    std::vector<float> melw;
+    std::vector<int4> desc(SIR_MAX_MELS);
+    for (int s = 0; s < SIR_MAX_MELS; ++s) {
+        const int j = order[s];
+        if (j >= nm) { desc[s] = make_int4(-1, 0, 0, 0); continue; }
+        desc[s] = make_int4(j, start[j], count[j], (int)melw.size());
+        for (int i = 0; i < count[j]; ++i) melw.push_back(fb[(size_t)(start[j] + i) * nm + j]);
+    }
+    if (melw.size() > 4096) {
+        sir_set_error("sir_create: the mel filterbank has %zu taps; only banded (triangular) banks of <= 4096 taps are built", melw.size());
+        delete h;
+        return SIR_EUNSUPPORTED;
+    }
+    h->mel_nnz = (int)melw.size();
+    melw.resize((melw.size() + 3) / 4 * 4 + 4, 0.0f);
+    h->feat_attr_set = false;
 
     int rc = upload(&h->tw512, tw512);
     if (rc == SIR_OK) rc = upload(&h->tw1024, tw1024);
     if (rc == SIR_OK) rc = upload(&h->window, window);
     if (rc == SIR_OK) rc = upload(&h->melw, melw);
-    if (rc == SIR_OK) rc = upload(&h->mel_start, start);
+    if (rc == SIR_OK) rc = upload(&h->mel_desc, desc);
     if (rc == SIR_OK) rc = upload(&h->status, std::vector<unsigned int>(64, 0u));
     if (rc == SIR_OK) rc = sir_check_hip(hipEventCreateWithFlags(&h->cluster_done, hipEventDisableTiming), "hipEventCreate");
     if (rc != SIR_OK) { sir_destroy(h); return rc; }
@@ -111,7 +130,7 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
 extern "C" int sir_destroy(sir_handle* h) {
     if (!h) return SIR_OK;
     (void)hipFree(h->tw512); (void)hipFree(h->tw1024); (void)hipFree(h->window);
-    (void)hipFree(h->melw); (void)hipFree(h->mel_start); (void)hipFree(h->status);
+    (void)hipFree(h->melw); (void)hipFree(h->mel_desc); (void)hipFree(h->status);
     if (h->cluster_done) (void)hipEventDestroy(h->cluster_done);
     for (auto& t : h->resample_tables) { (void)hipFree(t.taps); (void)hipFree(t.first); }
     for (auto& r : h->prof_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }

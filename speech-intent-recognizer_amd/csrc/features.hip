@@ -1,31 +1,49 @@
-// Fused feature kernels: waveform batch -> normalised, zero-padded log-mel [B][n_mels][t_pad].
+// Fused feature kernel: waveform batch -> normalised, zero-padded log-mel [B][n_mels][t_pad], ONE launch.
 //
 // Replaces (per clip, on CPU, one at a time in the reference):
 //   torchaudio MelSpectrogram + AmplitudeToDB + z-norm   scripts/precompute_features.py:59-73
 //   pad/trim to 200 frames                                scripts/dataset.py:109-113
+//   SpecAugment bands / time_shift / add_noise            scripts/dataset.py:160-176, scripts/augment.py:6-28, :82-96
 //
-// Kernel 1 (feat_frames): one workgroup = 16 consecutive frames of one utterance, 4 waves, each
-//   wave transforms one frame at a time: 1024 real samples (reflect-padded, Hann-windowed on load)
-//   are packed into 512 complex points, 8 per lane, and run through three radix-8 passes
-//   (register butterflies, two exchanges through a private per-wave LDS slab -- no workgroup barrier
-//   inside the frame loop), then untangled to the 513-bin power spectrum, reduced by the sparse
-//   HTK mel filterbank (tap-major table staged in LDS), log-compressed and collected in an LDS tile
-//   that is written out in 64-byte row segments together with (count, mean, M2) of the chunk.
-//   Twiddles / window are per-lane constants and live in registers for the whole workgroup.
-// Kernel 2 (feat_normalise): merges the chunk statistics (Chan), applies the whole-utterance
-//   (x-mean)/(std_unbiased+1e-5), SpecAugment masks if given, and zero-fills the padding frames.
-//
-// HBM traffic per utterance (algorithmic): L*4 B read (L*2 for PCM16) + n_mels*t_pad*4 B written;
-// the un-normalised dB tile makes one extra round trip that stays in L2/MALL (24 KB per 3 s clip).
+// feat_utt_kernel: one workgroup of 16 waves owns ONE utterance and walks its frames 16 at a time ("rounds"):
+//   * FFT: wave w transforms frame 16 r + w.  1024 real samples (reflect-padded, Hann-windowed on load, the next
+//     round's samples already in flight) are packed into 512 complex points, 8 per lane, and run through three
+//     radix-8 passes (register butterflies, two exchanges through the wave's private LDS slab -- no workgroup
+//     barrier inside the transform), then untangled to the 513-bin power spectrum, written to row w of P.
+//   * mel: after one barrier all 16 spectra of the round are in LDS and the 1024 threads split the 16 x 64
+//     (frame, filter) dot products one each: a thread walks only ITS filter's taps (2 ... 41 of them; the
+//     filterbank is stored compact), filters are sorted by length so the four filters a wave handles are equally
+//     long, and lanes that read P differ in the frame (row stride 513 words: a different bank each).  This is
+//     1000 multiply-adds per frame instead of the 64 x 41 padded ones of a lane-per-filter loop.
+//   * log-compress: the thread keeps its dB value of every round IN A REGISTER (10 rounds = 160 frames; 5 s clips are
+//     157 frames), so the utterance's whole [64 x T] dB tile lives in the register file.  After the last round the
+//     workgroup reduces mean and unbiased variance over it (two passes, double-precision combine) and every thread
+//     stores (x - mean) / (std + 1e-5) of its own values with the SpecAugment bands and the zero padding (64-byte row
+//     segments): no second kernel, no statistics round trip through L2, no tile in LDS -- which leaves room to
+//     double-buffer P, so a round costs ONE workgroup barrier.
+//     Clips longer than 160 frames (only the single-file predict surface feeds those) park their dB values in the
+//     output rows instead and the same workgroup re-reads them for the two passes (same CU, same L1: no
+//     inter-workgroup visibility involved).
+// LDS traffic is what bounds the transform (PMC: the LDS pipe was busy 45 % of the first fused version, 29 % of that
+// bank conflicts), hence: every exchange read is a single ds_read_b64 (`volatile`: hipcc otherwise pairs them into
+// ds_read2_b64, which moves HALF the bytes per LDS cycle and banks mod 32 in 16-lane groups); the second exchange uses a
+// stride-68 XOR-swizzled layout that is conflict-free for its 16-lane ds_write_b64 groups AND its 32-lane ds_read_b64
+// groups; the untangle partner Z[512-k] comes from lane (64 - lane) by ds_bpermute instead of a store + load.
+// HBM traffic per utterance (algorithmic): L*4 B read (L*2 for PCM16) + n_mels*t_pad*4 B written.
 #include <stdint.h>
 #include "sir_internal.h"
 
 namespace {
 
-constexpr int FPC = SIR_FRAMES_PER_CHUNK;
-constexpr int WAVES = 4;
-constexpr int XS = 72;           // padded stride (complex) of the radix-8 exchange slabs: conflict-free
+constexpr int NW = 16;           // waves per workgroup = frames per round
+constexpr int THREADS = NW * 64;
+constexpr int XS = 72;           // first exchange: row stride (complex) -- conflict-free 64-bank ds_read_b64 in pass 2
+constexpr int XS2 = 68;          // second exchange: row stride (complex), with the XOR swizzle of ex2_index
 constexpr int XBUF = 8 * XS;     // complex slots per wave
+constexpr int PROW = 514;        // words per power-spectrum row: the 16 frames of a filter sit on 16 different banks
+constexpr int TW2S = 10;         // row stride (complex) of the pass-2 twiddle table in LDS
+constexpr int RMAX = 10;         // rounds whose dB values a thread keeps in registers
+constexpr int TILE_T = RMAX * NW;   // = 160 frames
 constexpr float AMIN = 1e-10f;
 constexpr float NORM_EPS = 1e-5f;
 
@@ -33,9 +51,9 @@ struct FeatTables {
     const float2* tw512;
     const float2* tw1024;
     const float* window;
-    const float* melw;
-    const int* mel_start;
-    int max_taps;
+    const float* melw;           // compact filter weights, filter after filter, taps ascending in frequency
+    const int4* mel_desc;        // [64] per SLOT (filters sorted by tap count): {filter, first bin, taps, offset into melw}
+    int mel_nnz;
     int n_mels;
 };
 
@@ -51,6 +69,47 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
+
+// slot of element (row k2, j, m1) in the second exchange: (j, m1) -> (j ^ (m1 >> 1)) + 8 m1 is injective, the 16 lanes
+// (k2 in {2g, 2g+1}, m1) of a ds_write_b64 group land on 16 different bank pairs mod 32, and the 32 lanes (k2, j2 in
+// {4g .. 4g+3}) of a ds_read_b64 group on 32 different bank pairs mod 64 (row stride 68: 136 words = 8 mod 64)
+__device__ __forceinline__ int ex2_index(int k2, int j, int m1) { return k2 * XS2 + ((j ^ (m1 >> 1)) + 8 * m1); }
+
+// Eight single ds_read_b64 + their wait in ONE asm statement (cdna_hip_programming.md 5.7 form (i)): hipcc pairs plain --
+// and volatile -- adjacent LDS loads into ds_read2_b64 / ds_read2st64_b64, which move half the bytes per LDS cycle.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)p; }   // LDS byte offset of a __shared__ pointer
+
+// v[m] = *(base + m * STRIDE_BYTES), m = 0..7
+template <int STRIDE_BYTES>
+__device__ __forceinline__ void lds_read8(unsigned base, float2 (&v)[8]) {
+    f32x2 r0, r1, r2, r3, r4, r5, r6, r7;
+    asm volatile(
+        "ds_read_b64 %0, %8 offset:%9\n\tds_read_b64 %1, %8 offset:%10\n\tds_read_b64 %2, %8 offset:%11\n\t"
+        "ds_read_b64 %3, %8 offset:%12\n\tds_read_b64 %4, %8 offset:%13\n\tds_read_b64 %5, %8 offset:%14\n\t"
+        "ds_read_b64 %6, %8 offset:%15\n\tds_read_b64 %7, %8 offset:%16\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+        : "v"(base), "i"(0 * STRIDE_BYTES), "i"(1 * STRIDE_BYTES), "i"(2 * STRIDE_BYTES), "i"(3 * STRIDE_BYTES),
+          "i"(4 * STRIDE_BYTES), "i"(5 * STRIDE_BYTES), "i"(6 * STRIDE_BYTES), "i"(7 * STRIDE_BYTES)
+        : "memory");
+    v[0] = make_float2(r0.x, r0.y); v[1] = make_float2(r1.x, r1.y); v[2] = make_float2(r2.x, r2.y); v[3] = make_float2(r3.x, r3.y);
+    v[4] = make_float2(r4.x, r4.y); v[5] = make_float2(r5.x, r5.y); v[6] = make_float2(r6.x, r6.y); v[7] = make_float2(r7.x, r7.y);
+}
+// v[m] = *(base[m >> 1] + m * STRIDE_BYTES): the XOR-swizzled second exchange (one base per value of m >> 1)
+template <int STRIDE_BYTES>
+__device__ __forceinline__ void lds_read8x4(unsigned b0, unsigned b1, unsigned b2, unsigned b3, float2 (&v)[8]) {
+    f32x2 r0, r1, r2, r3, r4, r5, r6, r7;
+    asm volatile(
+        "ds_read_b64 %0, %8 offset:%12\n\tds_read_b64 %1, %8 offset:%13\n\tds_read_b64 %2, %9 offset:%14\n\t"
+        "ds_read_b64 %3, %9 offset:%15\n\tds_read_b64 %4, %10 offset:%16\n\tds_read_b64 %5, %10 offset:%17\n\t"
+        "ds_read_b64 %6, %11 offset:%18\n\tds_read_b64 %7, %11 offset:%19\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+        : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "i"(0 * STRIDE_BYTES), "i"(1 * STRIDE_BYTES), "i"(2 * STRIDE_BYTES),
+          "i"(3 * STRIDE_BYTES), "i"(4 * STRIDE_BYTES), "i"(5 * STRIDE_BYTES), "i"(6 * STRIDE_BYTES), "i"(7 * STRIDE_BYTES)
+        : "memory");
+    v[0] = make_float2(r0.x, r0.y); v[1] = make_float2(r1.x, r1.y); v[2] = make_float2(r2.x, r2.y); v[3] = make_float2(r3.x, r3.y);
+    v[4] = make_float2(r4.x, r4.y); v[5] = make_float2(r5.x, r5.y); v[6] = make_float2(r6.x, r6.y); v[7] = make_float2(r7.x, r7.y);
+}
 
 // forward 8-point DFT, natural order in and out (decimation in frequency)
 __device__ __forceinline__ void dft8(float2 (&v)[8]) {
@@ -68,19 +127,22 @@ __device__ __forceinline__ void dft8(float2 (&v)[8]) {
     v[1] = cadd(c0, c1); v[5] = csub(c0, c1); v[3] = cadd(c2, c3); v[7] = csub(c2, c3);
 }
 
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
+__device__ __forceinline__ unsigned fmix32(unsigned x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
 }
-// standard normal, a pure function of (seed, utterance, sample index): every frame that touches a
-// sample sees the same noise value
-__device__ __forceinline__ float gauss_at(unsigned long long seed, int b, int i) {
-    unsigned long long r = splitmix64(seed ^ splitmix64(((unsigned long long)(unsigned)b << 32) | (unsigned)i));
-    float u1 = (float)((unsigned)(r >> 40) + 1u) * (1.0f / 16777216.0f);
-    float u2 = (float)((unsigned)r & 0xFFFFFFu) * (1.0f / 16777216.0f);
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+// Two independent standard normals, a pure function of (seed, utterance, sample PAIR index p): samples 2p and 2p+1 of the
+// clip take .x and .y, so every frame that touches a sample sees the same noise value (Box-Muller on two 24-bit
+// uniforms from a counter hash; hardware log2 / sqrt / sin / cos: ~1e-6 absolute, far below the sigma <= 1e-2 it scales).
+// Restated on the host in tests/host_rng.py.
+__device__ __forceinline__ float2 gauss_pair(unsigned long long seed, int b, int p) {
+    const unsigned k = fmix32((unsigned)seed ^ ((unsigned)p * 0x9E3779B1u) ^ ((unsigned)b * 0x85EBCA77u));
+    const unsigned a = fmix32(k ^ (unsigned)(seed >> 32));
+    const unsigned c = fmix32(a + 0x632BE5ABu + (unsigned)p);
+    const float u1 = (float)((a >> 8) + 1u) * (1.0f / 16777216.0f);      // (0, 1]
+    const float u2 = (float)(c >> 8) * (1.0f / 16777216.0f);             // [0, 1)  (revolutions)
+    const float r = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), logf = log2
+    return make_float2(r * __builtin_amdgcn_cosf(u2), r * __builtin_amdgcn_sinf(u2));
 }
 
 template <typename T> __device__ __forceinline__ float to_f32(T v);
@@ -96,10 +158,67 @@ __device__ __forceinline__ float fetch(const T* __restrict__ x, int L, int i, in
     if (AUG) {
         int s = i - shift;
         float v = (s >= 0 && s < L) ? to_f32<T>(x[s]) : 0.0f;
-        if (sigma > 0.0f) v += sigma * gauss_at(seed, b, i);
+        if (sigma > 0.0f) {
+            const float2 g = gauss_pair(seed, b, i >> 1);
+            v += sigma * ((i & 1) ? g.y : g.x);
+        }
         return v;
     }
     return to_f32<T>(x[i]);
+}
+
+// the 16 samples of one lane for frame t (pairs (i0, i0 + 1), i0 = base + 2 (lane + 64 j)), un-windowed
+template <typename T, bool AUG>
+__device__ __forceinline__ void load_frame(const T* __restrict__ x, int L, int t, int lane, int shift, float sigma,
+                                           unsigned long long seed, int b, float2 (&s)[8]) {
+    const int base = t * SIR_HOP - SIR_HOP;         // first padded sample of the frame, in clip coordinates
+    const bool interior = base >= 0 && base + SIR_NFFT <= L;          // wave-uniform: no reflection in this frame
+    const bool paired = (reinterpret_cast<uintptr_t>(x) & (2 * sizeof(T) - 1)) == 0;   // row starts on a sample-pair boundary
+    if (interior && !AUG && !paired) {              // odd row stride / offset view: two scalar loads per pair
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const T* q = x + base + 2 * (lane + 64 * j);
+            s[j] = make_float2(to_f32<T>(q[0]), to_f32<T>(q[1]));
+        }
+        return;
+    }
+    if (interior && !AUG) {
+        if (sizeof(T) == 4) {
+            const float2* p = reinterpret_cast<const float2*>(x + base) + lane;       // base is even: 8-byte aligned rows
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = p[64 * j];
+        } else {
+            const unsigned* p = reinterpret_cast<const unsigned*>(x + base) + lane;   // two PCM16 samples per word
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned w = p[64 * j];
+                s[j] = make_float2((float)(short)(w & 0xFFFFu) * (1.0f / 32768.0f), (float)(short)(w >> 16) * (1.0f / 32768.0f));
+            }
+        }
+        return;
+    }
+    if (interior && AUG) {                          // shifted reads + ONE noise pair per lane and j (i0 is even)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i0 = base + 2 * (lane + 64 * j), s0 = i0 - shift;
+            float2 v;
+            v.x = (s0 >= 0 && s0 < L) ? to_f32<T>(x[s0]) : 0.0f;
+            v.y = (s0 + 1 >= 0 && s0 + 1 < L) ? to_f32<T>(x[s0 + 1]) : 0.0f;
+            if (sigma > 0.0f) {
+                const float2 g = gauss_pair(seed, b, i0 >> 1);
+                v.x += sigma * g.x;
+                v.y += sigma * g.y;
+            }
+            s[j] = v;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                   // first / last frames: reflect padding, element by element
+        const int i0 = base + 2 * (lane + 64 * j);
+        s[j].x = fetch<T, AUG>(x, L, i0, shift, sigma, seed, b);
+        s[j].y = fetch<T, AUG>(x, L, i0 + 1, shift, sigma, seed, b);
+    }
 }
 
 __device__ __forceinline__ void wave_fence() {
@@ -114,247 +233,241 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-template <typename WT, bool AUG>
-__global__ __launch_bounds__(256) void feat_frames_kernel(
-    const WT* __restrict__ wave, long long wave_stride, const int32_t* __restrict__ lengths, int max_len,
-    float* __restrict__ out, int t_pad, float4* __restrict__ stats, int nchunks, FeatTables tb, AugArgs aug) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* xall = reinterpret_cast<float2*>(smem);                    // [WAVES][XBUF]
-    float* melw = reinterpret_cast<float*>(xall + WAVES * XBUF);       // [max_taps][64]
-    float* tile = melw + tb.max_taps * 64;                             // [64][FPC+1]
-    float* red = tile + 64 * (FPC + 1);                                // [16]
-
-    const int b = blockIdx.y, chunk = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int L = lengths[b];
-    if (L > max_len) L = max_len;
-    const int T = (L > SIR_HOP) ? 1 + L / SIR_HOP : 0;
-    const int t0 = chunk * FPC;
-    if (t0 >= T) {                                  // block-uniform: nothing to do for this chunk
-        if (tid == 0) stats[(size_t)b * nchunks + chunk] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
-    for (int i = tid; i < tb.max_taps * 64; i += 256) melw[i] = tb.melw[i];
-
-    // per-lane constants, reused for every frame of this wave
-    float2 tw1[8], tw2[8], twu[8];
-    float win[16];
-    const int m1p = lane & 7;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        tw1[k] = tb.tw512[(lane * k) & 511];            // W512^(n1*k2)
-        tw2[k] = tb.tw512[(8 * m1p * k) & 511];         // W64^(m1*j2)
-        twu[k] = tb.tw1024[lane + 64 * k];              // W1024^k, k = lane + 64*j1
-        win[2 * k] = tb.window[2 * (lane + 64 * k)];
-        win[2 * k + 1] = tb.window[2 * (lane + 64 * k) + 1];
-    }
-    const int mel_start = (lane < tb.n_mels) ? tb.mel_start[lane] : 0;
-    const WT* x = wave + (size_t)b * wave_stride;
-    int shift = 0;
-    float sigma = 0.0f;
-    if (AUG) {
-        if (aug.shift) shift = aug.shift[b];
-        if (aug.sigma) sigma = aug.sigma[b];
-    }
+// workgroup sum of one float per thread, combined in double (deterministic order); every thread gets the result
+__device__ __forceinline__ double block_sum(float v, double* red, int lane, int wv) {
+    v = wave_sum(v);
+    __syncthreads();                                 // red is reused across calls
+    if (lane == 0) red[wv] = (double)v;
     __syncthreads();
-
-    float2* xb = xall + wv * XBUF;
-    float* pb = reinterpret_cast<float*>(xb);           // power spectrum aliases the slab
-    for (int fl = wv; fl < FPC; fl += WAVES) {
-        const int t = t0 + fl;
-        if (t >= T) {                                   // wave-uniform
-            tile[lane * (FPC + 1) + fl] = 0.0f;
-            continue;
-        }
-        float2 v[8];
-        const int base = t * SIR_HOP - SIR_HOP;         // first padded sample of the frame, in clip coords
+    double s = 0.0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int i0 = base + 2 * (lane + 64 * j);
-            // __fmul_rn: keep the window product un-fused so every template variant rounds alike
-            v[j].x = __fmul_rn(fetch<WT, AUG>(x, L, i0, shift, sigma, aug.seed, b), win[2 * j]);
-            v[j].y = __fmul_rn(fetch<WT, AUG>(x, L, i0 + 1, shift, sigma, aug.seed, b), win[2 * j + 1]);
-        }
-        // pass 1: DFT over n2 (stride 64), twiddle W512^(n1*k2)
-        dft8(v);
-#pragma unroll
-        for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw1[k]);
-        wave_fence();
-#pragma unroll
-        for (int k = 0; k < 8; ++k) xb[k * XS + lane] = v[k];
-        wave_fence();
-        {   // pass 2: lane = (k2, m1): DFT over m2, twiddle W64^(m1*j2)
-            const int k2 = lane >> 3;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = xb[k2 * XS + m1p + 8 * m];
-            dft8(v);
-#pragma unroll
-            for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw2[k]);
-            wave_fence();
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xb[k2 * XS + j + 9 * m1p] = v[j];
-            wave_fence();
-        }
-        {   // pass 3: lane = k2 + 8*j2: DFT over m1 -> Z[lane + 64*j1]
-            const int k2 = lane & 7, j2 = lane >> 3;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = xb[k2 * XS + j2 + 9 * m];
-            dft8(v);
-            wave_fence();
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xb[lane + 64 * j] = v[j];
-            wave_fence();
-        }
-        // untangle the packed real transform: X[k] = E[k] + W1024^k * O[k], power = |X|^2
-        float p[8];
-        float p512 = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = lane + 64 * j;
-            const float2 z = v[j];
-            const float2 zp = xb[(512 - k) & 511];
-            const float2 e = make_float2(0.5f * (z.x + zp.x), 0.5f * (z.y - zp.y));
-            const float2 d = make_float2(z.x - zp.x, z.y + zp.y);            // z - conj(zp)
-            const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);            // d / (2i)
-            const float2 w = cmul(twu[j], o);
-            const float xr = e.x + w.x, xi = e.y + w.y;
-            p[j] = xr * xr + xi * xi;
-            if (k == 0) { const float n = z.x - z.y; p512 = n * n; }          // X[512] = Re Z0 - Im Z0
-        }
-        wave_fence();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pb[lane + 64 * j] = p[j];
-        if (lane == 0) pb[512] = p512;
-        wave_fence();
-        // sparse HTK mel filterbank: lane = filter, taps ascending in frequency
-        float acc = 0.0f;
-        for (int i = 0; i < tb.max_taps; ++i) {
-            int k = mel_start + i;
-            k = k > 512 ? 512 : k;
-            acc = fmaf(melw[i * 64 + lane], pb[k], acc);
-        }
-        wave_fence();
-        // the 1e-10 clamp is exact in the reference (silence -> exactly -100 dB)
-        const float db = (acc <= AMIN) ? -100.0f : 10.0f * log10f(acc);
-        tile[lane * (FPC + 1) + fl] = db;
-    }
-    __syncthreads();
-
-    // chunk statistics over the valid (mel, frame) entries, two-pass inside the chunk
-    const int nv = (T - t0) < FPC ? (T - t0) : FPC;
-    const float cnt = (float)(nv * tb.n_mels);
-    float s = 0.0f;
-    for (int idx = tid; idx < 64 * FPC; idx += 256) {
-        const int mel = idx / FPC, f = idx % FPC;
-        if (mel < tb.n_mels && f < nv) s += tile[mel * (FPC + 1) + f];
-    }
-    s = wave_sum(s);
-    if (lane == 0) red[wv] = s;
-    __syncthreads();
-    const float mean = (red[0] + red[1] + red[2] + red[3]) / cnt;
-    float q = 0.0f;
-    for (int idx = tid; idx < 64 * FPC; idx += 256) {
-        const int mel = idx / FPC, f = idx % FPC;
-        if (mel < tb.n_mels && f < nv) {
-            const float v = tile[mel * (FPC + 1) + f];
-            q += (v - mean) * (v - mean);
-            if (t0 + f < t_pad) out[((size_t)b * tb.n_mels + mel) * t_pad + t0 + f] = v;
-        }
-    }
-    q = wave_sum(q);
-    if (lane == 0) red[8 + wv] = q;
-    __syncthreads();
-    if (tid == 0)
-        stats[(size_t)b * nchunks + chunk] = make_float4(cnt, mean, red[8] + red[9] + red[10] + red[11], 0.f);
+    for (int i = 0; i < NW; ++i) s += red[i];
+    return s;
 }
 
-constexpr int NORM_ROWS = 16;
+template <typename WT, bool AUG>
+__global__ __launch_bounds__(THREADS) void feat_utt_kernel(
+    const WT* __restrict__ wave, long long wave_stride, const int32_t* __restrict__ lengths, int max_len,
+    float* __restrict__ out, float* __restrict__ db_out, int t_pad, FeatTables tb, AugArgs aug,
+    const int32_t* __restrict__ time_mask, const int32_t* __restrict__ freq_mask) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* xall = reinterpret_cast<float2*>(smem);                    // [NW][XBUF] exchange slabs
+    double* red = reinterpret_cast<double*>(xall + NW * XBUF);         // [NW] reduction scratch
+    float* Pbuf = reinterpret_cast<float*>(red + NW);                  // [2][NW][PROW] power spectra, by round parity
+    float* melw = Pbuf + 2 * NW * PROW;                                // [mel_nnz]
+    float2* winl = reinterpret_cast<float2*>(melw + ((tb.mel_nnz + 3) & ~3));   // [512] Hann window as sample pairs
+    float2* tw2l = winl + 512;                                         // [8][TW2S] W64^(m1 * j2), row m1 (stride 10: the 8 rows' 16-byte reads fall on disjoint banks)
 
-__global__ __launch_bounds__(256) void feat_normalise_kernel(
-    float* __restrict__ out, float* __restrict__ db_out, int t_pad, int n_mels,
-    const int32_t* __restrict__ lengths, int max_len, const float4* __restrict__ stats, int nchunks, const int32_t* __restrict__ time_mask,
-    const int32_t* __restrict__ freq_mask) {
-    const int b = blockIdx.y;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n_mels = tb.n_mels;
     int L = lengths[b];
     if (L > max_len) L = max_len;
-    const int T = (L > SIR_HOP) ? 1 + L / SIR_HOP : 0;
+    const int T = (L > SIR_HOP) ? 1 + L / SIR_HOP : 0;                 // L <= 512: the reference fails (reflect pad) -> zero row
     const int tv = T < t_pad ? T : t_pad;
-    // merge chunk statistics (Chan et al.) ONCE per workgroup: the double-precision divisions of the merge, repeated by
-    // every thread, were most of this kernel (a dozen elements per thread of actual work)
-    __shared__ float s_mean, s_denom;
-    if (threadIdx.x == 0) {
-        double n = 0.0, mean = 0.0, m2 = 0.0;
-        for (int c = 0; c < nchunks; ++c) {
-            const float4 st = stats[(size_t)b * nchunks + c];
-            if (st.x > 0.0f) {
-                const double nc = st.x, delta = (double)st.y - mean, tot = n + nc;
-                mean += delta * nc / tot;
-                m2 += (double)st.z + delta * delta * n * nc / tot;
-                n = tot;
+    float* orow = out + (size_t)b * n_mels * t_pad;
+    float* drow = db_out ? db_out + (size_t)b * n_mels * t_pad : nullptr;
+    const bool in_regs = T <= TILE_T;                                  // block-uniform
+    const int nrounds = (T + NW - 1) / NW;
+    // mel role of this thread: (frame of the round, filter slot); the four slots of a wave are equally long filters
+    const int mf = tid & 15;
+    const int4 md = tb.mel_desc[tid >> 4];                             // {filter, first bin, taps, offset}
+    float dbv[RMAX];                                                   // this thread's dB values: frame 16 r + mf of filter md.x
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) dbv[r] = 0.0f;
+
+    if (nrounds > 0) {
+        for (int i = tid; i < tb.mel_nnz; i += THREADS) melw[i] = tb.melw[i];
+        if (tid < 512) winl[tid] = reinterpret_cast<const float2*>(tb.window)[tid];
+        if (tid < 64) tw2l[(tid >> 3) * TW2S + (tid & 7)] = tb.tw512[(8 * (tid >> 3) * (tid & 7)) & 511];
+
+        // per-lane constants of the transform, reused for every frame of this wave (the window and the pass-2 twiddles,
+        // which only depend on lane & 7, live in LDS: 30 more registers per lane would spill at four waves per SIMD)
+        float2 tw1[8], twu[8];
+        const int m1p = lane & 7;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            tw1[k] = tb.tw512[(lane * k) & 511];            // W512^(n1*k2)
+            twu[k] = tb.tw1024[lane + 64 * k];              // W1024^k, k = lane + 64*j1
+        }
+        const WT* x = wave + (size_t)b * wave_stride;
+        int shift = 0;
+        float sigma = 0.0f;
+        if (AUG) {
+            if (aug.shift) shift = aug.shift[b];
+            if (aug.sigma) sigma = aug.sigma[b];
+        }
+        float2* xb = xall + wv * XBUF;
+        const int mirror = ((64 - lane) & 63) * 4;          // ds_bpermute address of the lane that holds Z[512 - k]
+        // LDS byte addresses of this lane's read columns (loop-invariant)
+        const unsigned a_win = lds_addr(winl + lane);
+        const unsigned a_p2 = lds_addr(xb + (lane >> 3) * XS + m1p);
+        unsigned a_p3[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a_p3[q] = lds_addr(xb + (lane & 7) * XS2 + ((lane >> 3) ^ q));
+
+        float2 nxt[8];
+        if (wv < T) load_frame<WT, AUG>(x, L, wv, lane, shift, sigma, aug.seed, b, nxt);
+        __syncthreads();                                    // mel weights and window are staged
+
+        for (int r = 0; r < nrounds; ++r) {
+            const int t = r * NW + wv;
+            float* P = Pbuf + (r & 1) * (NW * PROW);
+            if (t < T) {                                    // wave-uniform
+                float2 v[8];
+                lds_read8<64 * 8>(a_win, v);                // window pairs lane + 64 j
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    // __fmul_rn: keep the window product un-fused so every template variant rounds alike
+                    v[j].x = __fmul_rn(nxt[j].x, v[j].x);
+                    v[j].y = __fmul_rn(nxt[j].y, v[j].y);
+                }
+                if (t + NW < T) load_frame<WT, AUG>(x, L, t + NW, lane, shift, sigma, aug.seed, b, nxt);   // next round's samples
+                // pass 1: DFT over n2 (stride 64), twiddle W512^(n1*k2)
+                dft8(v);
+#pragma unroll
+                for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw1[k]);
+                wave_fence();
+#pragma unroll
+                for (int k = 0; k < 8; ++k) xb[k * XS + lane] = v[k];
+                wave_fence();
+                {   // pass 2: lane = (k2, m1): DFT over m2, twiddle W64^(m1*j2)
+                    const int k2 = lane >> 3;
+                    lds_read8<8 * 8>(a_p2, v);              // xb[k2 * XS + m1p + 8 m]
+                    dft8(v);
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw2l[TW2S * m1p + k]);
+                    wave_fence();
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xb[ex2_index(k2, j, m1p)] = v[j];
+                    wave_fence();
+                }
+                {   // pass 3: lane = k2 + 8*j2: DFT over m1 -> Z[lane + 64*j1]
+                    lds_read8x4<8 * 8>(a_p3[0], a_p3[1], a_p3[2], a_p3[3], v);   // xb[ex2_index(lane & 7, lane >> 3, m)]
+                    dft8(v);
+                }
+                // untangle the packed real transform: X[k] = E[k] + W1024^k * O[k], power = |X|^2, k = lane + 64 j.
+                // The partner Z[512 - k] is register 7 - j of lane 64 - lane (lane 0: its own register 8 - j, and Z[512] = Z[0]).
+                float* prow = P + wv * PROW;
+                float2 zm[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    zm[j].x = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(v[7 - j].x)));
+                    zm[j].y = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(v[7 - j].y)));
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float2 z = v[j];
+                    float2 zp = zm[j];
+                    if (lane == 0) zp = v[(8 - j) & 7];
+                    const float2 e = make_float2(0.5f * (z.x + zp.x), 0.5f * (z.y - zp.y));
+                    const float2 d = make_float2(z.x - zp.x, z.y + zp.y);            // z - conj(zp)
+                    const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);            // d / (2i)
+                    const float2 w = cmul(twu[j], o);
+                    const float xr = e.x + w.x, xi = e.y + w.y;
+                    prow[lane + 64 * j] = xr * xr + xi * xi;
+                }
+                if (lane == 0) { const float n = v[0].x - v[0].y; prow[512] = n * n; }       // X[512] = Re Z0 - Im Z0
+            }
+            __syncthreads();                                // all spectra of this round are in P (the other parity is free again)
+            // sparse HTK mel filterbank: thread = (frame mf, filter md.x), taps ascending in frequency
+            const int tm = r * NW + mf;
+            if (md.x >= 0 && tm < T) {
+                const float* pr = P + mf * PROW + md.y;
+                const float* wr = melw + md.w;
+                float acc = 0.0f;
+                for (int i = 0; i < md.z; ++i) acc = fmaf(wr[i], pr[i], acc);
+                // the 1e-10 clamp is exact in the reference (silence -> exactly -100 dB)
+                const float db = (acc <= AMIN) ? -100.0f : 10.0f * log10f(acc);
+                if (in_regs) {
+#pragma unroll
+                    for (int q = 0; q < RMAX; ++q) dbv[q] = (q == r) ? db : dbv[q];
+                } else if (tm < t_pad) {
+                    orow[(size_t)md.x * t_pad + tm] = db;   // long clip: dB parked in the output row
+                }
             }
         }
-        s_mean = (float)mean;
-        s_denom = (n > 1.0 ? (float)sqrt(m2 / (n - 1.0)) : 0.0f) + NORM_EPS;
+        __syncthreads();
     }
-    __syncthreads();
-    const float meanf = s_mean, denom = s_denom;
+
+    // ---- whole-utterance statistics (two passes) and the normalised, masked, zero-padded store ----------------------
+    // the statistics are over ALL frames of the clip (precompute_features.py:73 normalises before any trim); a clip
+    // longer than 160 frames has every frame parked in its output row (the host checks t_pad >= T for those)
+    float mean = 0.0f, denom = 1.0f;
+    const bool mine = md.x >= 0;
+    if (T > 0) {
+        float s = 0.0f;
+        if (in_regs) {
+            if (mine) {
+#pragma unroll
+                for (int q = 0; q < RMAX; ++q) if (q * NW + mf < T) s += dbv[q];
+            }
+        } else {
+            for (int idx = tid; idx < n_mels * tv; idx += THREADS) s += orow[(size_t)(idx / tv) * t_pad + idx % tv];
+        }
+        const double cnt = (double)n_mels * (in_regs ? T : tv);
+        mean = (float)(block_sum(s, red, lane, wv) / cnt);
+        float q2 = 0.0f;
+        if (in_regs) {
+            if (mine) {
+#pragma unroll
+                for (int q = 0; q < RMAX; ++q) if (q * NW + mf < T) { const float d = dbv[q] - mean; q2 += d * d; }
+            }
+        } else {
+            for (int idx = tid; idx < n_mels * tv; idx += THREADS) { const float d = orow[(size_t)(idx / tv) * t_pad + idx % tv] - mean; q2 += d * d; }
+        }
+        const double m2 = block_sum(q2, red, lane, wv);
+        denom = (cnt > 1.0 ? (float)sqrt(m2 / (cnt - 1.0)) : 0.0f) + NORM_EPS;
+    }
     int tm0 = 0, tmw = 0, fm0 = 0, fmw = 0;
     if (time_mask) { tm0 = time_mask[2 * b]; tmw = time_mask[2 * b + 1]; }
     if (freq_mask) { fm0 = freq_mask[2 * b]; fmw = freq_mask[2 * b + 1]; }
-    const int row0 = blockIdx.x * NORM_ROWS;
-    float* o = out + ((size_t)b * n_mels + row0) * t_pad;
-    float* dbo = db_out ? db_out + ((size_t)b * n_mels + row0) * t_pad : nullptr;
-    const int rows = (n_mels - row0) < NORM_ROWS ? (n_mels - row0) : NORM_ROWS;
-    if ((t_pad & 3) == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(db_out)) & 15) == 0) {
-        // four frames per thread and iteration (rows are 16-byte aligned)
-        const int q4 = t_pad >> 2;
-        for (int i4 = threadIdx.x; i4 < rows * q4; i4 += 256) {
-            const int r = i4 / q4, t0 = 4 * (i4 - r * q4), mel = row0 + r;
-            const bool fmasked = mel >= fm0 && mel < fm0 + fmw;
-            float4* op = reinterpret_cast<float4*>(o + (size_t)r * t_pad + t0);
-            float4 dbv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t0 < tv) dbv = *op;
-            float dbs[4] = {dbv.x, dbv.y, dbv.z, dbv.w}, vs[4];
+    if (in_regs) {
+        // every thread stores its own values: 16 lanes = 16 consecutive frames of one mel row (64-byte segments)
+        if (mine) {
+            const bool fmasked = md.x >= fm0 && md.x < fm0 + fmw;
+            float* o = orow + (size_t)md.x * t_pad;
+            float* dbo = drow ? drow + (size_t)md.x * t_pad : nullptr;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int t = t0 + e;
-                float v = 0.0f;
-                if (t < tv) {
-                    v = (dbs[e] - meanf) / denom;
-                    if ((t >= tm0 && t < tm0 + tmw) || fmasked) v = 0.0f;
-                } else dbs[e] = 0.0f;
-                vs[e] = v;
+            for (int q = 0; q < RMAX; ++q) {
+                const int t = q * NW + mf;
+                if (t < t_pad) {
+                    float v = 0.0f, d = 0.0f;
+                    if (t < tv) {
+                        d = dbv[q];
+                        v = (d - mean) / denom;
+                        if ((t >= tm0 && t < tm0 + tmw) || fmasked) v = 0.0f;
+                    }
+                    o[t] = v;
+                    if (dbo) dbo[t] = d;
+                }
             }
-            *op = make_float4(vs[0], vs[1], vs[2], vs[3]);
-            if (dbo) *reinterpret_cast<float4*>(dbo + (size_t)r * t_pad + t0) = make_float4(dbs[0], dbs[1], dbs[2], dbs[3]);
+            for (int t = RMAX * NW + mf; t < t_pad; t += NW) {       // padding beyond the register tile
+                o[t] = 0.0f;
+                if (dbo) dbo[t] = 0.0f;
+            }
         }
-        return;
-    }
-    for (int idx = threadIdx.x; idx < rows * t_pad; idx += 256) {
-        const int r = idx / t_pad, t = idx - r * t_pad;
-        float v = 0.0f, db = 0.0f;
-        if (t < tv) {
-            db = o[idx];
-            v = (db - meanf) / denom;
-            const int mel = row0 + r;
-            if ((t >= tm0 && t < tm0 + tmw) || (mel >= fm0 && mel < fm0 + fmw)) v = 0.0f;
+    } else {
+        for (int idx = tid; idx < n_mels * t_pad; idx += THREADS) {
+            const int mel = idx / t_pad, t = idx - mel * t_pad;
+            float v = 0.0f, d = 0.0f;
+            if (t < tv) {
+                d = orow[idx];
+                v = (d - mean) / denom;
+                if ((t >= tm0 && t < tm0 + tmw) || (mel >= fm0 && mel < fm0 + fmw)) v = 0.0f;
+            }
+            orow[idx] = v;
+            if (drow) drow[idx] = d;
         }
-        o[idx] = v;
-        if (dbo) dbo[idx] = db;
     }
 }
 
 }  // namespace
 
-static inline int feat_nchunks(int max_len) {
-    const int max_t = 1 + max_len / SIR_HOP;
-    return (max_t + FPC - 1) / FPC;
-}
-
 extern "C" size_t sir_features_workspace_bytes(const sir_handle* h, int batch, int max_len) {
     (void)h;
     if (batch <= 0 || max_len <= 0) return 0;
-    return sir_align_up((size_t)batch * feat_nchunks(max_len) * sizeof(float4), 256);
+    return 256;          // the fused kernel keeps its statistics on chip; a token size keeps the (workspace, bytes) contract
 }
 
 int sir_features_launch(sir_handle* h, const void* wave, int wave_dtype, int64_t wave_stride,
@@ -369,9 +482,17 @@ int sir_features_launch(sir_handle* h, const void* wave, int wave_dtype, int64_t
     }
     if (wave_dtype != SIR_WAVE_F32 && wave_dtype != SIR_WAVE_I16) { sir_set_error("sir_features_fwd: wave_dtype %d", wave_dtype); return SIR_EINVAL; }
     if (workspace_bytes < sir_features_workspace_bytes(h, batch, max_len)) { sir_set_error("sir_features_fwd: workspace too small"); return SIR_ENOMEM; }
-    if (batch > 65535) { sir_set_error("sir_features_fwd: batch > 65535"); return SIR_EINVAL; }
-    const int nchunks = feat_nchunks(max_len);
-    FeatTables tb{h->tw512, h->tw1024, h->window, h->melw, h->mel_start, h->max_taps, h->cfg.n_mels};
+    const size_t esz = wave_dtype == SIR_WAVE_F32 ? 4 : 2;
+    if (((uintptr_t)wave % esz) != 0) { sir_set_error("sir_features_fwd: waveform pointer is not aligned to its sample type"); return SIR_EINVAL; }
+    const int max_t = 1 + max_len / SIR_HOP;
+    if (max_t > TILE_T && max_t > t_pad) {
+        // a clip longer than the LDS tile parks its dB values in its output rows; the statistics of the reference are
+        // over ALL frames (precompute_features.py:73 normalises before any trim), so every frame needs a slot there
+        sir_set_error("sir_features_fwd: clips of up to %d frames need t_pad >= %d (or max_len <= %d samples)", max_t, max_t,
+                      TILE_T * SIR_HOP + SIR_HOP - 1);
+        return SIR_EUNSUPPORTED;
+    }
+    FeatTables tb{h->tw512, h->tw1024, h->window, h->melw, h->mel_desc, h->mel_nnz, h->cfg.n_mels};
     AugArgs ag{nullptr, nullptr, 0ull};
     bool wave_aug = false;
     const int32_t *tmask = nullptr, *fmask = nullptr;
@@ -380,24 +501,25 @@ int sir_features_launch(sir_handle* h, const void* wave, int wave_dtype, int64_t
         wave_aug = aug->shift || aug->noise_sigma;
         tmask = aug->time_mask; fmask = aug->freq_mask;
     }
-    float4* stats = reinterpret_cast<float4*>(workspace);
-    const size_t lds = (size_t)WAVES * XBUF * sizeof(float2) + (size_t)h->max_taps * 64 * sizeof(float) +
-                       64 * (FPC + 1) * sizeof(float) + 16 * sizeof(float);
-    dim3 grid(nchunks, batch), block(256);
-#define SIR_LAUNCH_FRAMES(TY, AUGF)                                                                          \
-    hipLaunchKernelGGL((feat_frames_kernel<TY, AUGF>), grid, block, lds, stream, (const TY*)wave,           \
-                       (long long)wave_stride, lengths, max_len, out, t_pad, stats, nchunks, tb, ag)
+    const size_t lds = (size_t)NW * XBUF * sizeof(float2) + NW * sizeof(double) + (size_t)2 * NW * PROW * sizeof(float) +
+                       (size_t)((h->mel_nnz + 3) & ~3) * sizeof(float) + (512 + 8 * TW2S) * sizeof(float2);
+    if (!h->feat_attr_set) {          // > 64 KB of dynamic LDS needs the opt-in, once per handle (= per device)
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)feat_utt_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)feat_utt_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)feat_utt_kernel<short, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)feat_utt_kernel<short, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        h->feat_attr_set = true;
+    }
+    dim3 grid(batch), block(THREADS);
+#define SIR_LAUNCH_FEAT(TY, AUGF)                                                                            \
+    hipLaunchKernelGGL((feat_utt_kernel<TY, AUGF>), grid, block, lds, stream, (const TY*)wave,              \
+                       (long long)wave_stride, lengths, max_len, out, db_out, t_pad, tb, ag, tmask, fmask)
     {
     SirProfScope prof(h, SIR_K_FEAT_FRAMES, stream);
-    if (wave_dtype == SIR_WAVE_F32) { if (wave_aug) SIR_LAUNCH_FRAMES(float, true); else SIR_LAUNCH_FRAMES(float, false); }
-    else { if (wave_aug) SIR_LAUNCH_FRAMES(short, true); else SIR_LAUNCH_FRAMES(short, false); }
+    if (wave_dtype == SIR_WAVE_F32) { if (wave_aug) SIR_LAUNCH_FEAT(float, true); else SIR_LAUNCH_FEAT(float, false); }
+    else { if (wave_aug) SIR_LAUNCH_FEAT(short, true); else SIR_LAUNCH_FEAT(short, false); }
     }
-#undef SIR_LAUNCH_FRAMES
-    SIR_HIP_TRY(hipGetLastError());
-    SirProfScope prof2(h, SIR_K_FEAT_NORM, stream);
-    dim3 grid2((h->cfg.n_mels + NORM_ROWS - 1) / NORM_ROWS, batch);
-    hipLaunchKernelGGL(feat_normalise_kernel, grid2, block, 0, stream, out, db_out, t_pad, h->cfg.n_mels, lengths, max_len,
-                       (const float4*)stats, nchunks, tmask, fmask);
+#undef SIR_LAUNCH_FEAT
     SIR_HIP_TRY(hipGetLastError());
     return SIR_OK;
 }

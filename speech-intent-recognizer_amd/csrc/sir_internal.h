@@ -11,7 +11,6 @@
 #define SIR_HOP 512
 #define SIR_NFREQ 513
 #define SIR_MAX_MELS 64
-#define SIR_FRAMES_PER_CHUNK 16   // frames handled by one workgroup of the frame kernel
 
 // kernels (or kernel groups) of the path, for sir_profile_*
 enum SirKernelId {
@@ -53,9 +52,10 @@ struct sir_handle {
     float2* tw512;      // exp(-2*pi*i*j/512),  j = 0..511
     float2* tw1024;     // exp(-2*pi*i*k/1024), k = 0..512
     float* window;      // [1024]
-    float* melw;        // [max_taps][64]  tap-major, zero padded
-    int* mel_start;     // [64] first FFT bin of each filter
-    int max_taps;
+    float* melw;        // compact filter weights: filter after filter, taps ascending in frequency (mel_nnz floats)
+    int4* mel_desc;     // [64] per slot, filters sorted by tap count: {filter (-1 = unused), first FFT bin, taps, offset into melw}
+    int mel_nnz;
+    bool feat_attr_set; // the feature kernel's dynamic-LDS opt-in has been made on this handle's device
     std::vector<sir_resample_table> resample_tables;   // built on first use of a rate pair
     // device word set to 1 by a GRU recurrence kernel whose inter-workgroup exchange timed out (its results are then
     // invalid); zeroed at creation, read and cleared by sir_check_status / sir_profile_collect

@@ -3,11 +3,11 @@ draws to the CPU oracle:
 
 * ``dropout_keep``  -- csrc/train_kernels.h ``dropout_keep(seed, idx, p)``: the keep mask of the inter-layer GRU dropout
   (reference models/models.py:26-33, ``nn.GRU(dropout=0.5)``), a pure function of (seed, element index);
-* ``gauss_noise``   -- csrc/features.hip ``gauss_at(seed, b, i)``: the N(0,1) sample added to sample i of utterance b by the
-  fused ``add_noise`` (reference scripts/augment.py:82-96).
+* ``gauss_noise``   -- csrc/features.hip ``gauss_pair(seed, b, i >> 1)``: the N(0,1) sample added to sample i of utterance b
+  by the fused ``add_noise`` (reference scripts/augment.py:82-96).
 
-Integer parts are bit-exact (uint64 wrap-around arithmetic); the Box-Muller transform is evaluated in float32 like the
-device does, so a noise value may differ from the device's by an ulp of logf / cosf (~1e-7 relative)."""
+Integer parts are bit-exact (wrap-around arithmetic); the Box-Muller transform uses the device's hardware log2 / sqrt /
+sin / cos there and numpy here, so a noise value may differ from the device's by ~1e-6 absolute (times sigma <= 1e-2)."""
 import numpy as np
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
@@ -31,19 +31,33 @@ def dropout_keep(seed, n, p):
     return u >= np.float32(p)
 
 
-def _splitmix64(x):
+def _fmix32(x):
+    x = x.astype(np.uint32)
     with np.errstate(over="ignore"):
-        x = x + np.uint64(0x9E3779B97F4A7C15)
-        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        return x ^ (x >> np.uint64(31))
+        x ^= x >> np.uint32(16)
+        x *= np.uint32(0x85EBCA6B)
+        x ^= x >> np.uint32(13)
+        x *= np.uint32(0xC2B2AE35)
+        x ^= x >> np.uint32(16)
+    return x
 
 
 def gauss_noise(seed, b, n):
-    """float32 [n]: the standard-normal stream of utterance ``b`` (sample indices 0..n-1)."""
-    i = np.arange(n, dtype=np.uint64)
-    key = (np.uint64(b) << np.uint64(32)) | i
-    r = _splitmix64(_u64(seed) ^ _splitmix64(key))
-    u1 = ((r >> np.uint64(40)).astype(np.uint32) + np.uint32(1)).astype(np.float32) * np.float32(1.0 / 16777216.0)
-    u2 = (r & np.uint64(0xFFFFFF)).astype(np.uint32).astype(np.float32) * np.float32(1.0 / 16777216.0)
-    return (np.sqrt(np.float32(-2.0) * np.log(u1)) * np.cos(np.float32(6.28318530717958647692) * u2)).astype(np.float32)
+    """float32 [n]: the standard-normal stream of utterance ``b`` (sample indices 0..n-1).  One Box-Muller draw per
+    sample PAIR p = i >> 1: sample 2p takes r*cos, sample 2p+1 takes r*sin (features.hip ``gauss_pair``)."""
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    lo, hi = np.uint32(seed & 0xFFFFFFFF), np.uint32(seed >> 32)
+    npair = (n + 1) // 2
+    p = np.arange(npair, dtype=np.uint32)
+    with np.errstate(over="ignore"):
+        k = _fmix32(lo ^ (p * np.uint32(0x9E3779B1)) ^ np.uint32((int(b) * 0x85EBCA77) & 0xFFFFFFFF))
+        a = _fmix32(k ^ hi)
+        c = _fmix32(a + np.uint32(0x632BE5AB) + p)
+    u1 = ((a >> np.uint32(8)) + np.uint32(1)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    u2 = (c >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    r = np.sqrt(np.float32(-1.38629436111989061883) * np.log2(u1)).astype(np.float32)
+    ang = (np.float64(2.0 * np.pi) * u2.astype(np.float64))
+    out = np.empty(2 * npair, dtype=np.float32)
+    out[0::2] = r * np.cos(ang).astype(np.float32)
+    out[1::2] = r * np.sin(ang).astype(np.float32)
+    return out[:n]

@@ -154,3 +154,27 @@ def test_spec_masks():
     exp[0, :, 10:25] = 0
     exp[1, 50:60, :] = 0
     assert torch.equal(out, exp)
+
+
+def test_clips_longer_than_the_lds_tile():
+    """> 160 frames (only the single-file predict surface feeds such clips, max_duration = 600 s there): the dB values are
+    parked in the output rows and the same workgroup normalises them over ALL frames (precompute_features.py:73 runs
+    before any trim).  Mixed with a short clip in the same batch; PCM16 input as well."""
+    w = synth.synth_clips(3, 200000, seed=91)
+    lengths = [200000, 130001, 40000]
+    t_pad = 1 + 200000 // 512
+    for dtype, scale in ((torch.float32, 1.0), (torch.int16, 32767.0)):
+        waves = [(w[i, : lengths[i]] * scale).round() if dtype == torch.int16 else w[i, : lengths[i]] for i in range(3)]
+        out, db = _run(waves, lengths, t_pad=t_pad, dtype=dtype)
+        for i in range(3):
+            src = waves[i].to(torch.float32) / (32768.0 if dtype == torch.int16 else 1.0)
+            ref = features_ref.extract_features_f32(src, max_duration=1e9, stages=True)
+            t = ref["db"].shape[1]
+            assert t == 1 + lengths[i] // 512
+            assert _close(db[i, :, :t], ref["db"]).all(), (i, np.abs(db[i, :, :t].numpy() - ref["db"].numpy()).max())
+            assert _close(out[i, :, :t], ref["norm"]).all(), i
+            assert (out[i, :, t:] == 0).all() and (db[i, :, t:] == 0).all()
+    # a long clip needs a slot per frame in the output: refused, not silently wrong
+    from sir_amd import _native
+    with pytest.raises(_native.SirError):
+        _run([w[0]], [200000], t_pad=200)
