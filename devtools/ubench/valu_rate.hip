@@ -15,8 +15,10 @@ __global__ void probe(float* out, int iters, unsigned long long* cyc) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) a[i] = fmaf(a[i], m, c);
-            if (MIX == 1) { asm volatile("s_add_u32 %0, %0, 1" : "+s"(s)); asm volatile("s_add_u32 %0, %0, 1" : "+s"(s)); }
+            for (int i = 0; i < 8; ++i) {
+                if (MIX == 0) a[i] = fmaf(a[i], m, c);                               // compiler may pack pairs into v_pk_fma_f32
+                else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));   // scalar fma, one per accumulator
+            }
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();

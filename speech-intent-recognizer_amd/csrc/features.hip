@@ -63,12 +63,17 @@ struct AugArgs {
     unsigned long long seed;
 };
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+// Complex values are 2-vectors so that every complex add / sub / scale is ONE packed instruction (v_pk_add_f32,
+// v_pk_mul_f32, v_pk_fma_f32 with op_sel / neg modifiers for the swaps and sign flips): a VALU instruction costs the same
+// ~4 issue cycles whether it carries one float or two per lane, and this kernel is issue-bound (PMC: SQ_ACTIVE_INST_ANY
+// = the kernel's duration at 4.3 cycles per instruction).
+typedef float cf32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf32 CF(float2 a) { return cf32{a.x, a.y}; }
+__device__ __forceinline__ cf32 swp(cf32 a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ cf32 mul_mi(cf32 a) { return cf32{a.y, -a.x}; }                       // a * (-i)
+__device__ __forceinline__ cf32 cmul(cf32 a, cf32 b) {                                           // a * b
+    return cf32{a.x, a.x} * b + cf32{a.y, a.y} * cf32{-b.y, b.x};
 }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
 
 // slot of element (row k2, j, m1) in the second exchange: (j, m1) -> (j ^ (m1 >> 1)) + 8 m1 is injective, the 16 lanes
 // (k2 in {2g, 2g+1}, m1) of a ds_write_b64 group land on 16 different bank pairs mod 32, and the 32 lanes (k2, j2 in
@@ -77,12 +82,12 @@ __device__ __forceinline__ int ex2_index(int k2, int j, int m1) { return k2 * XS
 
 // Eight single ds_read_b64 + their wait in ONE asm statement (cdna_hip_programming.md 5.7 form (i)): hipcc pairs plain --
 // and volatile -- adjacent LDS loads into ds_read2_b64 / ds_read2st64_b64, which move half the bytes per LDS cycle.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef cf32 f32x2;
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)p; }   // LDS byte offset of a __shared__ pointer
 
 // v[m] = *(base + m * STRIDE_BYTES), m = 0..7
 template <int STRIDE_BYTES>
-__device__ __forceinline__ void lds_read8(unsigned base, float2 (&v)[8]) {
+__device__ __forceinline__ void lds_read8(unsigned base, cf32 (&v)[8]) {
     f32x2 r0, r1, r2, r3, r4, r5, r6, r7;
     asm volatile(
         "ds_read_b64 %0, %8 offset:%9\n\tds_read_b64 %1, %8 offset:%10\n\tds_read_b64 %2, %8 offset:%11\n\t"
@@ -92,12 +97,11 @@ __device__ __forceinline__ void lds_read8(unsigned base, float2 (&v)[8]) {
         : "v"(base), "i"(0 * STRIDE_BYTES), "i"(1 * STRIDE_BYTES), "i"(2 * STRIDE_BYTES), "i"(3 * STRIDE_BYTES),
           "i"(4 * STRIDE_BYTES), "i"(5 * STRIDE_BYTES), "i"(6 * STRIDE_BYTES), "i"(7 * STRIDE_BYTES)
         : "memory");
-    v[0] = make_float2(r0.x, r0.y); v[1] = make_float2(r1.x, r1.y); v[2] = make_float2(r2.x, r2.y); v[3] = make_float2(r3.x, r3.y);
-    v[4] = make_float2(r4.x, r4.y); v[5] = make_float2(r5.x, r5.y); v[6] = make_float2(r6.x, r6.y); v[7] = make_float2(r7.x, r7.y);
+    v[0] = r0; v[1] = r1; v[2] = r2; v[3] = r3; v[4] = r4; v[5] = r5; v[6] = r6; v[7] = r7;
 }
 // v[m] = *(base[m >> 1] + m * STRIDE_BYTES): the XOR-swizzled second exchange (one base per value of m >> 1)
 template <int STRIDE_BYTES>
-__device__ __forceinline__ void lds_read8x4(unsigned b0, unsigned b1, unsigned b2, unsigned b3, float2 (&v)[8]) {
+__device__ __forceinline__ void lds_read8x4(unsigned b0, unsigned b1, unsigned b2, unsigned b3, cf32 (&v)[8]) {
     f32x2 r0, r1, r2, r3, r4, r5, r6, r7;
     asm volatile(
         "ds_read_b64 %0, %8 offset:%12\n\tds_read_b64 %1, %8 offset:%13\n\tds_read_b64 %2, %9 offset:%14\n\t"
@@ -107,24 +111,23 @@ __device__ __forceinline__ void lds_read8x4(unsigned b0, unsigned b1, unsigned b
         : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "i"(0 * STRIDE_BYTES), "i"(1 * STRIDE_BYTES), "i"(2 * STRIDE_BYTES),
           "i"(3 * STRIDE_BYTES), "i"(4 * STRIDE_BYTES), "i"(5 * STRIDE_BYTES), "i"(6 * STRIDE_BYTES), "i"(7 * STRIDE_BYTES)
         : "memory");
-    v[0] = make_float2(r0.x, r0.y); v[1] = make_float2(r1.x, r1.y); v[2] = make_float2(r2.x, r2.y); v[3] = make_float2(r3.x, r3.y);
-    v[4] = make_float2(r4.x, r4.y); v[5] = make_float2(r5.x, r5.y); v[6] = make_float2(r6.x, r6.y); v[7] = make_float2(r7.x, r7.y);
+    v[0] = r0; v[1] = r1; v[2] = r2; v[3] = r3; v[4] = r4; v[5] = r5; v[6] = r6; v[7] = r7;
 }
 
 // forward 8-point DFT, natural order in and out (decimation in frequency)
-__device__ __forceinline__ void dft8(float2 (&v)[8]) {
+__device__ __forceinline__ void dft8(cf32 (&v)[8]) {
     const float R = 0.70710678118654752440f;
-    float2 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
-    float2 a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
-    float2 a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
-    float2 a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
-    a5 = make_float2((a5.x + a5.y) * R, (a5.y - a5.x) * R);      // * W8^1
+    cf32 a0 = v[0] + v[4], a4 = v[0] - v[4];
+    cf32 a1 = v[1] + v[5], a5 = v[1] - v[5];
+    cf32 a2 = v[2] + v[6], a6 = v[2] - v[6];
+    cf32 a3 = v[3] + v[7], a7 = v[3] - v[7];
+    a5 = (a5 + mul_mi(a5)) * R;                                  // * W8^1 = (x + y, y - x) / sqrt 2
     a6 = mul_mi(a6);                                             // * W8^2
-    a7 = make_float2((a7.y - a7.x) * R, -(a7.x + a7.y) * R);     // * W8^3
-    float2 b0 = cadd(a0, a2), b2 = csub(a0, a2), b1 = cadd(a1, a3), b3 = mul_mi(csub(a1, a3));
-    float2 c0 = cadd(a4, a6), c2 = csub(a4, a6), c1 = cadd(a5, a7), c3 = mul_mi(csub(a5, a7));
-    v[0] = cadd(b0, b1); v[4] = csub(b0, b1); v[2] = cadd(b2, b3); v[6] = csub(b2, b3);
-    v[1] = cadd(c0, c1); v[5] = csub(c0, c1); v[3] = cadd(c2, c3); v[7] = csub(c2, c3);
+    a7 = (mul_mi(a7) - a7) * R;                                  // * W8^3 = (y - x, -x - y) / sqrt 2
+    cf32 b0 = a0 + a2, b2 = a0 - a2, b1 = a1 + a3, b3 = mul_mi(a1 - a3);
+    cf32 c0 = a4 + a6, c2 = a4 - a6, c1 = a5 + a7, c3 = mul_mi(a5 - a7);
+    v[0] = b0 + b1; v[4] = b0 - b1; v[2] = b2 + b3; v[6] = b2 - b3;
+    v[1] = c0 + c1; v[5] = c0 - c1; v[3] = c2 + c3; v[7] = c2 - c3;
 }
 
 __device__ __forceinline__ unsigned fmix32(unsigned x) {
@@ -170,7 +173,7 @@ __device__ __forceinline__ float fetch(const T* __restrict__ x, int L, int i, in
 // the 16 samples of one lane for frame t (pairs (i0, i0 + 1), i0 = base + 2 (lane + 64 j)), un-windowed
 template <typename T, bool AUG>
 __device__ __forceinline__ void load_frame(const T* __restrict__ x, int L, int t, int lane, int shift, float sigma,
-                                           unsigned long long seed, int b, float2 (&s)[8]) {
+                                           unsigned long long seed, int b, cf32 (&s)[8]) {
     const int base = t * SIR_HOP - SIR_HOP;         // first padded sample of the frame, in clip coordinates
     const bool interior = base >= 0 && base + SIR_NFFT <= L;          // wave-uniform: no reflection in this frame
     const bool paired = (reinterpret_cast<uintptr_t>(x) & (2 * sizeof(T) - 1)) == 0;   // row starts on a sample-pair boundary
@@ -178,13 +181,13 @@ __device__ __forceinline__ void load_frame(const T* __restrict__ x, int L, int t
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const T* q = x + base + 2 * (lane + 64 * j);
-            s[j] = make_float2(to_f32<T>(q[0]), to_f32<T>(q[1]));
+            s[j] = cf32{to_f32<T>(q[0]), to_f32<T>(q[1])};
         }
         return;
     }
     if (interior && !AUG) {
         if (sizeof(T) == 4) {
-            const float2* p = reinterpret_cast<const float2*>(x + base) + lane;       // base is even: 8-byte aligned rows
+            const cf32* p = reinterpret_cast<const cf32*>(x + base) + lane;           // base is even: 8-byte aligned rows
 #pragma unroll
             for (int j = 0; j < 8; ++j) s[j] = p[64 * j];
         } else {
@@ -192,7 +195,7 @@ __device__ __forceinline__ void load_frame(const T* __restrict__ x, int L, int t
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const unsigned w = p[64 * j];
-                s[j] = make_float2((float)(short)(w & 0xFFFFu) * (1.0f / 32768.0f), (float)(short)(w >> 16) * (1.0f / 32768.0f));
+                s[j] = cf32{(float)(short)(w & 0xFFFFu), (float)(short)(w >> 16)} * (1.0f / 32768.0f);
             }
         }
         return;
@@ -201,13 +204,12 @@ __device__ __forceinline__ void load_frame(const T* __restrict__ x, int L, int t
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int i0 = base + 2 * (lane + 64 * j), s0 = i0 - shift;
-            float2 v;
+            cf32 v;
             v.x = (s0 >= 0 && s0 < L) ? to_f32<T>(x[s0]) : 0.0f;
             v.y = (s0 + 1 >= 0 && s0 + 1 < L) ? to_f32<T>(x[s0 + 1]) : 0.0f;
             if (sigma > 0.0f) {
                 const float2 g = gauss_pair(seed, b, i0 >> 1);
-                v.x += sigma * g.x;
-                v.y += sigma * g.y;
+                v += sigma * cf32{g.x, g.y};
             }
             s[j] = v;
         }
@@ -251,12 +253,13 @@ __global__ __launch_bounds__(THREADS) void feat_utt_kernel(
     float* __restrict__ out, float* __restrict__ db_out, int t_pad, FeatTables tb, AugArgs aug,
     const int32_t* __restrict__ time_mask, const int32_t* __restrict__ freq_mask) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* xall = reinterpret_cast<float2*>(smem);                    // [NW][XBUF] exchange slabs
+    cf32* xall = reinterpret_cast<cf32*>(smem);                        // [NW][XBUF] exchange slabs
     double* red = reinterpret_cast<double*>(xall + NW * XBUF);         // [NW] reduction scratch
     float* Pbuf = reinterpret_cast<float*>(red + NW);                  // [2][NW][PROW] power spectra, by round parity
     float* melw = Pbuf + 2 * NW * PROW;                                // [mel_nnz]
-    float2* winl = reinterpret_cast<float2*>(melw + ((tb.mel_nnz + 3) & ~3));   // [512] Hann window as sample pairs
-    float2* tw2l = winl + 512;                                         // [8][TW2S] W64^(m1 * j2), row m1 (stride 10: the 8 rows' 16-byte reads fall on disjoint banks)
+    cf32* winl = reinterpret_cast<cf32*>(melw + ((tb.mel_nnz + 3) & ~3));       // [512] Hann window as sample pairs
+    cf32* twul = winl + 512;                                           // [512] -i/2 * W1024^k, the untangle twiddles
+    cf32* tw2l = twul + 512;                                           // [8][TW2S] W64^(m1 * j2), row m1 (stride 10: the 8 rows' 16-byte reads fall on disjoint banks)
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -278,18 +281,19 @@ __global__ __launch_bounds__(THREADS) void feat_utt_kernel(
 
     if (nrounds > 0) {
         for (int i = tid; i < tb.mel_nnz; i += THREADS) melw[i] = tb.melw[i];
-        if (tid < 512) winl[tid] = reinterpret_cast<const float2*>(tb.window)[tid];
-        if (tid < 64) tw2l[(tid >> 3) * TW2S + (tid & 7)] = tb.tw512[(8 * (tid >> 3) * (tid & 7)) & 511];
+        if (tid < 512) {
+            winl[tid] = reinterpret_cast<const cf32*>(tb.window)[tid];
+            // X[k] = (z + conj zp)/2 + (-i/2 W1024^k)(z - conj zp)
+            twul[tid] = 0.5f * mul_mi(CF(tb.tw1024[tid]));
+        }
+        if (tid < 64) tw2l[(tid >> 3) * TW2S + (tid & 7)] = CF(tb.tw512[(8 * (tid >> 3) * (tid & 7)) & 511]);
 
-        // per-lane constants of the transform, reused for every frame of this wave (the window and the pass-2 twiddles,
-        // which only depend on lane & 7, live in LDS: 30 more registers per lane would spill at four waves per SIMD)
-        float2 tw1[8], twu[8];
+        // per-lane constants of the transform, reused for every frame of this wave (the window, the pass-2 twiddles -- which only
+        // depend on lane & 7 -- and the untangle twiddles live in LDS: 46 more registers per lane would spill at four waves per SIMD)
+        cf32 tw1[8];
         const int m1p = lane & 7;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            tw1[k] = tb.tw512[(lane * k) & 511];            // W512^(n1*k2)
-            twu[k] = tb.tw1024[lane + 64 * k];              // W1024^k, k = lane + 64*j1
-        }
+        for (int k = 0; k < 8; ++k) tw1[k] = CF(tb.tw512[(lane * k) & 511]);        // W512^(n1*k2)
         const WT* x = wave + (size_t)b * wave_stride;
         int shift = 0;
         float sigma = 0.0f;
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(THREADS) void feat_utt_kernel(
             if (aug.shift) shift = aug.shift[b];
             if (aug.sigma) sigma = aug.sigma[b];
         }
-        float2* xb = xall + wv * XBUF;
+        cf32* xb = xall + wv * XBUF;
         const int mirror = ((64 - lane) & 63) * 4;          // ds_bpermute address of the lane that holds Z[512 - k]
         // LDS byte addresses of this lane's read columns (loop-invariant)
         const unsigned a_win = lds_addr(winl + lane);
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(THREADS) void feat_utt_kernel(
 #pragma unroll
         for (int q = 0; q < 4; ++q) a_p3[q] = lds_addr(xb + (lane & 7) * XS2 + ((lane >> 3) ^ q));
 
-        float2 nxt[8];
+        cf32 nxt[8];
         if (wv < T) load_frame<WT, AUG>(x, L, wv, lane, shift, sigma, aug.seed, b, nxt);
         __syncthreads();                                    // mel weights and window are staged
 
@@ -314,14 +318,10 @@ __global__ __launch_bounds__(THREADS) void feat_utt_kernel(
             const int t = r * NW + wv;
             float* P = Pbuf + (r & 1) * (NW * PROW);
             if (t < T) {                                    // wave-uniform
-                float2 v[8];
+                cf32 v[8];
                 lds_read8<64 * 8>(a_win, v);                // window pairs lane + 64 j
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    // __fmul_rn: keep the window product un-fused so every template variant rounds alike
-                    v[j].x = __fmul_rn(nxt[j].x, v[j].x);
-                    v[j].y = __fmul_rn(nxt[j].y, v[j].y);
-                }
+                for (int j = 0; j < 8; ++j) v[j] = nxt[j] * v[j];       // (a product only: nothing to fuse)
                 if (t + NW < T) load_frame<WT, AUG>(x, L, t + NW, lane, shift, sigma, aug.seed, b, nxt);   // next round's samples
                 // pass 1: DFT over n2 (stride 64), twiddle W512^(n1*k2)
                 dft8(v);
@@ -346,26 +346,21 @@ __global__ __launch_bounds__(THREADS) void feat_utt_kernel(
                     lds_read8x4<8 * 8>(a_p3[0], a_p3[1], a_p3[2], a_p3[3], v);   // xb[ex2_index(lane & 7, lane >> 3, m)]
                     dft8(v);
                 }
-                // untangle the packed real transform: X[k] = E[k] + W1024^k * O[k], power = |X|^2, k = lane + 64 j.
-                // The partner Z[512 - k] is register 7 - j of lane 64 - lane (lane 0: its own register 8 - j, and Z[512] = Z[0]).
+                // untangle the packed real transform: X[k] = (z + conj zp)/2 + (-i/2 W1024^k)(z - conj zp), power = |X|^2,
+                // k = lane + 64 j.  The partner zp = Z[512 - k] is register 7 - j of lane 64 - lane (lane 0: its own
+                // register 8 - j, and Z[512] = Z[0]).
                 float* prow = P + wv * PROW;
-                float2 zm[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    zm[j].x = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(v[7 - j].x)));
-                    zm[j].y = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(v[7 - j].y)));
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float2 z = v[j];
-                    float2 zp = zm[j];
-                    if (lane == 0) zp = v[(8 - j) & 7];
-                    const float2 e = make_float2(0.5f * (z.x + zp.x), 0.5f * (z.y - zp.y));
-                    const float2 d = make_float2(z.x - zp.x, z.y + zp.y);            // z - conj(zp)
-                    const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);            // d / (2i)
-                    const float2 w = cmul(twu[j], o);
-                    const float xr = e.x + w.x, xi = e.y + w.y;
-                    prow[lane + 64 * j] = xr * xr + xi * xi;
+                    const cf32 z = v[j];
+                    cf32 zc;
+                    zc.x = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(v[7 - j].x)));
+                    zc.y = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(v[7 - j].y)));
+                    if (lane == 0) zc = v[(8 - j) & 7];
+                    zc.y = -zc.y;                           // conj(zp)
+                    const cf32 xk = 0.5f * (z + zc) + cmul(z - zc, twul[lane + 64 * j]);
+                    const cf32 sq = xk * xk;
+                    prow[lane + 64 * j] = sq.x + sq.y;
                 }
                 if (lane == 0) { const float n = v[0].x - v[0].y; prow[512] = n * n; }       // X[512] = Re Z0 - Im Z0
             }
@@ -502,7 +497,7 @@ int sir_features_launch(sir_handle* h, const void* wave, int wave_dtype, int64_t
         tmask = aug->time_mask; fmask = aug->freq_mask;
     }
     const size_t lds = (size_t)NW * XBUF * sizeof(float2) + NW * sizeof(double) + (size_t)2 * NW * PROW * sizeof(float) +
-                       (size_t)((h->mel_nnz + 3) & ~3) * sizeof(float) + (512 + 8 * TW2S) * sizeof(float2);
+                       (size_t)((h->mel_nnz + 3) & ~3) * sizeof(float) + (1024 + 8 * TW2S) * sizeof(float2);
     if (!h->feat_attr_set) {          // > 64 KB of dynamic LDS needs the opt-in, once per handle (= per device)
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)feat_utt_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)feat_utt_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
