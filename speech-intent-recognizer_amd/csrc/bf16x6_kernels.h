@@ -365,6 +365,18 @@ constexpr int conv_bf16x6_row_bytes(int PC, bool pad = true) {
 }
 constexpr size_t conv_bf16x6_lds_bytes(int PR, int PC, bool pad = true) { return (size_t)3 * (8 * PR + 2) * conv_bf16x6_row_bytes(PC, pad); }
 
+// LDS image of the channel-split kernel (conv3x3_bf16x6_ns_kernel): per plane and tile row, the FIRST 16-byte halves
+// (channels 0-7 of the 16-channel chunk) of all 4 PC + 2 pixels, then their SECOND halves -- row = 2 (4 PC + 2)
+// sixteen-byte slots = 4 (mod 8) slots, no padding.  A ds_read_b128 serves the lanes in the groups {0-3,12-15,20-27},
+// {4-11,16-19,28-31} (+32 for the second half-wave); with the 8x4 patch bit layout of an A fragment a group is
+// rows {0,1,6,7} x columns {0,1} + rows {2,3,4,5} x columns {2,3} (or the complement), and slot = 4 row + column
+// (mod 16) gives those 16 lanes 16 different slots of the 256-byte bank line for every tap and patch offset.  The
+// pixel-major image (32- or padded 48-byte pixels) it replaces had 2-way conflicts on two lane pairs per group
+// (PMC r01: SQ_LDS_BANK_CONFLICT = 50 % of the LDS cycles of conv2) unless every row was padded, which cost the third
+// workgroup per CU.  This one is both conflict-free and a third smaller (conv2: 32,640 B against 48,960 B).
+constexpr int conv_ns_row_bytes(int PC) { return 2 * (4 * PC + 2) * 16; }
+constexpr size_t conv_ns_lds_bytes(int PR, int PC) { return (size_t)3 * (8 * PR + 2) * conv_ns_row_bytes(PC); }
+
 __device__ __forceinline__ void prep_conv_w_bf16x3_elem(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin, int cout, int idx) {
     const int total = cin * 9 * cout;
     if (idx >= total) return;
@@ -572,15 +584,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(
 //   KNOCK (tools/bench_conv.hip timing experiments; 0 in the product): bit 0 = weights loaded once,
 //   bit 1 = input tile staged once.
 // ------------------------------------------------------------------------------------------
-// MINB = workgroups per CU the register allocation must allow (3 where the accumulators leave room), PAD = padded LDS rows
-template <int CIN, int COUT, int PR, int PC, int OUT_MODE, int KNOCK = 0, int MINB = 2, bool PAD = true>
+// MINB = workgroups per CU the register allocation must allow (3 where the accumulators leave room)
+template <int CIN, int COUT, int PR, int PC, int OUT_MODE, int KNOCK = 0, int MINB = 2>
 __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpb, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp, float2* __restrict__ stats) {
-    constexpr int WN = COUT / 32, WM = 4 / WN, MT = PR * PC / WM, CK = 16, PSB = 48;
+    constexpr int WN = COUT / 32, WM = 4 / WN, MT = PR * PC / WM, CK = 16, PSB = 16;   // PSB: bytes between neighbouring pixels of a half-row
     constexpr int GS = MT < 4 ? MT : 4;                     // patches per MFMA group (independent accumulators in flight)
     constexpr int TR = 8 * PR, TC = 4 * PC, TROWS = TR + 2, TCOLS = TC + 2;
-    constexpr int RSB = conv_bf16x6_row_bytes(PC, PAD);
+    constexpr int RSB = conv_ns_row_bytes(PC), HSB = TCOLS * 16;   // row stride; offset of the second 16-byte halves inside a row
     constexpr int PLANE = TROWS * RSB;
     constexpr int G = (CIN / 16) * 9;
     static_assert(COUT % 32 == 0 && WN <= 4 && 4 % WN == 0 && (PR * PC) % WM == 0 && MT % GS == 0 && CIN % CK == 0, "tile shape");
@@ -592,7 +604,7 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
     const int pxl = (m & 1) + 2 * ((m >> 2) & 1);
     const int pyl = ((m >> 1) & 1) + 2 * ((m >> 3) & 1) + 4 * ((m >> 4) & 1);
     // patch pi = wm * MT + mt: row block pi % PR, column block pi / PR (column blocks ascend with mt)
-    const int lane_off = pyl * RSB + pxl * PSB + h * 16;
+    const int lane_off = pyl * RSB + pxl * PSB + h * HSB;
     int nvalid = 0;                                         // patches of this wave that start inside the image (a prefix)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) nvalid += (tx0 + 4 * ((wm * MT + mt) / PR) < W) ? 1 : 0;
@@ -615,7 +627,10 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
         if (!(KNOCK & 2) || cc == 0) {
         if (cc) __syncthreads();
         for (int idx = tid; idx < TROWS * TCOLS * 4; idx += 256) {
-            const int pix = idx >> 2, part = idx & 3;
+            // 16 consecutive lanes = 8 neighbouring pixels x the two 8-byte halves of ONE 16-byte slot class (hsel): their
+            // ds_write_b64 group covers 128 contiguous bytes (lanes that mixed both classes met on 8 of the 32 banks)
+            const int hsel = idx / (2 * TROWS * TCOLS), rem = idx - hsel * (2 * TROWS * TCOLS);
+            const int pix = rem >> 1, part = 2 * hsel + (rem & 1);
             const int tyy = pix / TCOLS, txx = pix - tyy * TCOLS;
             const int gy = ty0 - 1 + tyy, gx = tx0 - 1 + txx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -623,7 +638,7 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
                 v = *reinterpret_cast<const float4*>(xb + ((size_t)gy * W + gx) * CIN + cc * CK + part * 4);
             uint2 hh, mm, ll;
             split3_quad(v, hh, mm, ll);
-            unsigned char* d = ldsb + tyy * RSB + txx * PSB + part * 8;
+            unsigned char* d = ldsb + tyy * RSB + txx * PSB + (part >> 1) * HSB + (part & 1) * 8;
             *reinterpret_cast<uint2*>(d) = hh;
             *reinterpret_cast<uint2*>(d + PLANE) = mm;
             *reinterpret_cast<uint2*>(d + 2 * PLANE) = ll;

@@ -207,10 +207,10 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
             constexpr size_t lds = conv_bf16x6_lds_bytes(4, 2);
             if (sir_conv_ns())
 if (occ)
-            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 0, 0, 3, false>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), conv_bf16x6_lds_bytes(4, 2, false), st, a1,
+            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 0, 0, 3>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), conv_ns_lds_bytes(4, 2), st, a1,
                                (const unsigned short*)wcb2, bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
             else
-            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 0>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), lds, st, a1,
+            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 0>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), conv_ns_lds_bytes(4, 2), st, a1,
                                (const unsigned short*)wcb2, bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
             else
             hipLaunchKernelGGL((conv3x3_bf16x6_kernel<32, 64, 4, 2, 0, 2>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), lds, st, a1,
@@ -236,10 +236,10 @@ if (occ)
         constexpr size_t lds = conv_bf16x6_lds_bytes(2, 4);
         if (sir_conv_ns())
 if (occ)
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 1, 0, 3, true>), dim3((d.wp2 + 7) / 8, 1, B), dim3(256), conv_bf16x6_lds_bytes(2, 2), st, a2,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 1, 0, 3>), dim3((d.wp2 + 7) / 8, 1, B), dim3(256), conv_ns_lds_bytes(2, 2), st, a2,
                            (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, fuse_x0 ? (float2*)xs : (float2*)nullptr);
         else
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 4, 1>), dim3((d.wp2 + 15) / 16, 1, B), dim3(256), lds, st, a2,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 4, 1>), dim3((d.wp2 + 15) / 16, 1, B), dim3(256), conv_ns_lds_bytes(2, 4), st, a2,
                            (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)nullptr);
         else
         hipLaunchKernelGGL((conv3x3_bf16x6_kernel<64, 128, 2, 4, 1, 2>), dim3((d.wp2 + 15) / 16, 1, B), dim3(256), lds, st, a2,

@@ -276,7 +276,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
         constexpr size_t lds = conv_bf16x6_lds_bytes(4, 2);
         { SirProfScope prof(h, SIR_K_T_CONV2, st);
         if (sir_conv_ns())
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 2, 0, 3, false>), dim3(d.c2gx, 1, B), dim3(256), conv_bf16x6_lds_bytes(4, 2, false), st, (const float*)p.a1,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 2, 0, 3>), dim3(d.c2gx, 1, B), dim3(256), conv_ns_lds_bytes(4, 2), st, (const float*)p.a1,
                            (const unsigned short*)p.wcb2, (const float*)nullptr, (const float*)nullptr, p.z2, 32, d.wp1, 16, d.wp2, p.stats);
         else
         hipLaunchKernelGGL((conv3x3_bf16x6_kernel<32, 64, 4, 2, 2, 2>), dim3(d.c2gx, 1, B), dim3(256), lds, st, (const float*)p.a1,
@@ -292,7 +292,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
         constexpr size_t lds = conv_bf16x6_lds_bytes(2, 4);
         { SirProfScope prof(h, SIR_K_T_CONV3, st);
         if (sir_conv_ns())
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 2, 0, 3, true>), dim3(d.c3fx, 1, B), dim3(256), conv_bf16x6_lds_bytes(2, 2), st, (const float*)p.a2,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 2, 0, 3>), dim3(d.c3fx, 1, B), dim3(256), conv_ns_lds_bytes(2, 2), st, (const float*)p.a2,
                            (const unsigned short*)p.wcb3, (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats);
         else
         hipLaunchKernelGGL((conv3x3_bf16x6_kernel<64, 128, 2, 4, 2, 2>), dim3(d.c3gx, 1, B), dim3(256), lds, st, (const float*)p.a2,
@@ -583,7 +583,7 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
         // (data-gradient weights p.wcb3t: train_prep_kernel of the forward)
         constexpr size_t ldsd = conv_bf16x6_lds_bytes(2, 4);
         if (sir_conv_ns())
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<128, 64, 2, 4, 2, 0, 3, true>), dim3(d.c3gx, 1, B), dim3(256), ldsd, st, (const float*)p.dz3,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<128, 64, 2, 4, 2, 0, 3>), dim3(d.c3gx, 1, B), dim3(256), conv_ns_lds_bytes(2, 4), st, (const float*)p.dz3,
                            (const unsigned short*)p.wcb3t, (const float*)nullptr, (const float*)nullptr, p.da2, 16, d.wp2, 8, d.wp3,
                            (float2*)nullptr);
         else
@@ -646,7 +646,7 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
         // (data-gradient weights p.wcb2t: train_prep_kernel of the forward)
         constexpr size_t ldsd = conv_bf16x6_lds_bytes(4, 2);
         if (sir_conv_ns())
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 32, 4, 2, 2, 0, 3, false>), dim3(d.c2gx, 1, B), dim3(256), conv_bf16x6_lds_bytes(4, 2, false), st, (const float*)p.dz2,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 32, 4, 2, 2, 0, 3>), dim3(d.c2gx, 1, B), dim3(256), conv_ns_lds_bytes(4, 2), st, (const float*)p.dz2,
                            (const unsigned short*)p.wcb2t, (const float*)nullptr, (const float*)nullptr, p.da1, 32, d.wp1, 16, d.wp2,
                            (float2*)nullptr);
         else
