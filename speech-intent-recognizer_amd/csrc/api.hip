@@ -51,6 +51,7 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     h->tw512 = nullptr; h->tw1024 = nullptr; h->window = nullptr; h->melw = nullptr; h->mel_desc = nullptr;
     h->status = nullptr;
     h->cluster_done = nullptr; h->cluster_stream = nullptr; h->cluster_pending = false;
+    h->attr_gemm_v3 = h->attr_gru_quad = h->attr_gru_bwd = h->attr_tn = h->attr_wgrad = false;
     h->cfg = *cfg;
     h->cfg.window = nullptr;
     h->cfg.mel_fb = nullptr;

@@ -62,126 +62,3 @@ __device__ __forceinline__ float gp_load_sc1(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_load_dword ... sc1
 }
 
-// xbuf  [npairs*2 dirs][2 parity][2 halves][GP_BW][128] 8-byte {tag, value} granules, zeroed before every launch
-// status[0] is set to 1 if a spin times out (results are then invalid; never happens when all pairs are resident)
-template <bool SAVE>
-__global__ __launch_bounds__(GP_THREADS) void gru_pair_kernel(
-    const float* __restrict__ gi, const float* __restrict__ whh0, const float* __restrict__ whh1,
-    const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ y, int B, int S,
-    float* __restrict__ gates, float* xbuf, unsigned int* flags, unsigned int* status, int dbg_nowait = 0) {
-    extern __shared__ __attribute__((aligned(16))) float plds[];
-    gp_f4* wl4 = reinterpret_cast<gp_f4*>(plds);                       // [GP_LDS4][3][threads] float4
-    float* hs = plds + GP_LDS4 * 3 * GP_THREADS * 4;                           // h[b][256]
-    const int dir = blockIdx.y, pair = blockIdx.x >> 1, half = blockIdx.x & 1;
-    const int b0 = pair * GP_BW;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int kp = lane & (GP_KP - 1), ul = (wv << 4) | (lane >> 2);      // unit within this half
-    const int u = half * GP_UH + ul;                                     // hidden unit (0..255)
-    const float* __restrict__ whh = dir ? whh1 : whh0;                   // original [768][256] layout
-    const float* __restrict__ bhh = dir ? bhh1 : bhh0;
-    const int pd = pair * 2 + dir;
-    unsigned long long* xg = reinterpret_cast<unsigned long long*>(xbuf) + (size_t)pd * 2 * 2 * GP_BW * GP_UH;   // granules
-
-    // this thread's weights: gate rows g*256+u, k in [64*kp, 64*kp+64): resident for the whole sequence
-    gp_f4 wr[GP_REG4][3];
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        const gp_f4* src = reinterpret_cast<const gp_f4*>(whh + (size_t)(g * 256 + u) * 256 + kp * (GP_K4 * 4));
-#pragma unroll
-        for (int i = 0; i < GP_REG4; ++i) wr[i][g] = src[i];
-#pragma unroll
-        for (int i = 0; i < GP_LDS4; ++i) wl4[(i * 3 + g) * GP_THREADS + tid] = src[GP_REG4 + i];
-    }
-    const float bh_r = bhh[u], bh_z = bhh[256 + u], bh_n = bhh[512 + u];
-    for (int i = tid; i < GP_BW * GP_HB; i += GP_THREADS) hs[i] = 0.0f;
-    const int bme = kp;                                      // lane kp finishes utterance kp of unit u
-    const bool finisher = true;
-    const bool bvalid = finisher && (b0 + bme) < B;
-    float hprev = 0.0f;
-    __syncthreads();
-
-    // gate pre-activations are fetched one step ahead: their HBM/L2 latency hides behind a whole step
-    float gr_n = 0.f, gz_n = 0.f, gn_n = 0.f;
-    if (bvalid) {
-        const float* g = gi + ((size_t)(b0 + bme) * S + (dir ? S - 1 : 0)) * 1536 + dir * 768;
-        gr_n = g[u]; gz_n = g[256 + u]; gn_n = g[512 + u];
-    }
-    for (int step = 0; step < S; ++step) {
-        const int t = dir ? (S - 1 - step) : step;
-        const float gr = gr_n, gz = gz_n, gn = gn_n;
-        if (bvalid && step + 1 < S) {
-            const int tn = dir ? (S - 2 - step) : step + 1;
-            const float* g = gi + ((size_t)(b0 + bme) * S + tn) * 1536 + dir * 768;
-            gr_n = g[u]; gz_n = g[256 + u]; gn_n = g[512 + u];
-        }
-        gp_f2 acc2[3][GP_BW];
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int bb = 0; bb < GP_BW; ++bb) acc2[g][bb] = (gp_f2)(0.0f, 0.0f);
-#pragma unroll
-        for (int i = 0; i < GP_REG4; ++i) {                      // register-resident weights
-            gp_f4 h4[GP_BW];
-#pragma unroll
-            for (int bb = 0; bb < GP_BW; ++bb) h4[bb] = *reinterpret_cast<const gp_f4*>(hs + bb * GP_HB + kp * GP_HP + i * 4);
-            gp_pkfma4(acc2[0], wr[i][0], h4); gp_pkfma4(acc2[1], wr[i][1], h4); gp_pkfma4(acc2[2], wr[i][2], h4);
-        }
-        // keep the LDS-resident weights IN LDS (do not let the compiler hoist these loop-invariant loads)
-        asm volatile("" ::: "memory");
-#pragma unroll 2
-        for (int i = 0; i < GP_LDS4; ++i) {                      // LDS-resident weights
-            gp_f4 h4[GP_BW];
-#pragma unroll
-            for (int bb = 0; bb < GP_BW; ++bb)
-                h4[bb] = *reinterpret_cast<const gp_f4*>(hs + bb * GP_HB + kp * GP_HP + (GP_REG4 + i) * 4);
-#pragma unroll
-            for (int g = 0; g < 3; ++g) gp_pkfma4(acc2[g], wl4[(i * 3 + g) * GP_THREADS + tid], h4);
-        }
-        // sum even/odd partial sums, then the 4 k-parts of each unit (lanes differing in bits 0..1)
-        float acc[3][GP_BW];
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int bb = 0; bb < GP_BW; ++bb) {
-                float v = acc2[g][bb].x + acc2[g][bb].y;
-                v += gp_quad_xor1(v);          // DPP quad_perm: no LDS crossbar trip
-                v += gp_quad_xor2(v);
-                acc[g][bb] = v;
-            }
-        float hr = bh_r, hz = bh_z, hn = bh_n;
-#pragma unroll
-        for (int bb = 0; bb < GP_BW; ++bb)
-            if (bb == bme) { hr += acc[0][bb]; hz += acc[1][bb]; hn += acc[2][bb]; }
-        const float r = sigmoidf_(gr + hr);
-        const float zg = sigmoidf_(gz + hz);
-        const float nn = tanhf(gn + r * hn);
-        const float hnew = (1.0f - zg) * nn + zg * hprev;
-        // exchange (R2 of the guide's hand-off recipe: the data IS the flag): every value travels as one
-        // naturally aligned 8-byte {tag = step+1, value} granule written by ONE write-through store; the
-        // consumer re-reads its granule until the tag matches.  One hop instead of store+flag+poll+load.
-        unsigned long long* gslot = xg + ((size_t)(step & 1) * 2 + half) * GP_BW * GP_UH;
-        const unsigned long long* gpeer = xg + ((size_t)(step & 1) * 2 + (half ^ 1)) * GP_BW * GP_UH;
-        hprev = hnew;
-        __hip_atomic_store(gslot + bme * GP_UH + ul, ((unsigned long long)(unsigned)(step + 1) << 32) | __float_as_uint(hnew),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (bvalid) {
-            y[((size_t)(b0 + bme) * S + t) * 512 + dir * 256 + u] = hnew;
-            if (SAVE) {
-                float* gs = gates + (((size_t)(b0 + bme) * S + t) * 2 + dir) * 1024;
-                gs[u] = r; gs[256 + u] = zg; gs[512 + u] = nn; gs[768 + u] = hn;
-            }
-        }
-        __syncthreads();                                                  // every wave is done reading hs
-        hs[gp_hidx(bme, u)] = hnew;                                       // own half of the new h
-        unsigned long long pv;
-        unsigned spins = 0;
-        while (((pv = __hip_atomic_load(gpeer + bme * GP_UH + ul, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) !=
-               (unsigned long long)(unsigned)(step + 1)) {
-            if (dbg_nowait) break;                                        // timing experiment only (wrong results)
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > GP_SPIN_LIMIT) { __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-        hs[gp_hidx(bme, (half ^ 1) * GP_UH + ul)] = __uint_as_float((unsigned)pv);
-        __syncthreads();
-    }
-}

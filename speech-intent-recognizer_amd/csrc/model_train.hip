@@ -87,12 +87,7 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     const size_t bw = (size_t)(B * 16 * d.wp1 / 64 + 64) * 128;          // bn backward partials, generous
     if (bw > st) st = bw;
     n[TB_STATS] = 2 * st;
-    n[TB_WP2] = 36 * 64 * 8;
-    n[TB_WP3] = 72 * 128 * 8;
-    n[TB_WHT] = 4 * 768 * 256;
-    n[TB_WR4] = 4 * 768 * 256;
-    n[TB_WP2T] = 72 * 32 * 8;
-    n[TB_WP3T] = 144 * 64 * 8;
+    n[TB_WP2] = n[TB_WP3] = n[TB_WHT] = n[TB_WR4] = n[TB_WP2T] = n[TB_WP3T] = 64;   // (slots of removed kernel generations; indices kept)
     n[TB_DY1] = B * S * 512;
     n[TB_DY0] = B * S * 512;
     n[TB_DGI] = B * S * 1536;
@@ -117,8 +112,8 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     n[TB_XS] = (B * S * 1024 * 3 + 1) / 2;                       // ushort count / 2 (sizes are in floats)
     n[TB_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512 + 1) / 2;
     n[TB_WCB] = ((size_t)2 * (3 * 32 * 9 * 64 + 3 * 64 * 9 * 128) + 1) / 2;
-    n[TB_GXB] = sir_gru_pair_xbuf_bytes(d.B) / 4;
-    n[TB_GFL] = sir_gru_pair_flag_bytes(d.B) / 4;
+    n[TB_GXB] = sir_gru_xbuf_bytes(d.B) / 4;
+    n[TB_GFL] = 64;
     n[TB_C1M] = 2 * C1_NMOM;
 }
 
@@ -132,11 +127,6 @@ size_t tws_layout(const TDims& d, size_t* off) {
     return pos;
 }
 
-const int kBnC[3] = {32, 64, 128}, kBnO[3] = {0, 32, 96};
-// BatchNorm backward sums from the pooled activations (bn_bwd_reduce_pooled_kernel) instead of the raw conv outputs
-const int bn_reduce_pooled = getenv("SIR_BN_REDUCE_POOLED") ? atoi(getenv("SIR_BN_REDUCE_POOLED")) : 1;
-// conv1 BatchNorm statistics and the mean terms of its weight gradient from 54 moments of the input (conv1_moments_kernel)
-const int conv1_moments = getenv("SIR_CONV1_MOMENTS") ? atoi(getenv("SIR_CONV1_MOMENTS")) : 1;
 
 #define KCHECK() SIR_HIP_TRY(hipGetLastError())
 
@@ -240,7 +230,6 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
             add(0, w->gru_w_ih[dir], p.wsl0 + (size_t)dir * 3 * 768 * 1024, 1024, 768, 384);
             add(0, w->gru_w_ih[2 + dir], p.wsl1 + (size_t)dir * 3 * 768 * 512, 512, 768, 192);
         }
-        for (int i = 0; i < 4; ++i) add(3, w->gru_w_hh[i], p.wr4 + (size_t)i * 768 * 256, 0, 0, 768);
         pj.block0[nj] = blocks;
         pj.njobs = nj;
         static_assert(PREP_MAX_JOBS >= 12, "job table");
@@ -251,36 +240,25 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     // conv1 block: statistics pass (recompute), finalize, then the fused conv+BN+ReLU+pool pass
     {
         SirProfScope prof(h, SIR_K_T_CONV1, st);
-        const dim3 g1(d.c1gx, d.c1gy, B);
-        if (conv1_moments) {                           // statistics from 54 moments of the input, no conv1 recompute
-            const int tiles = d.c1gx * d.c1gy;
-            int per_img = (2048 + B - 1) / B;             // workgroups per image: >= 2048 in all when the batch allows it
-            per_img = per_img < 1 ? 1 : (per_img > tiles ? tiles : per_img);
-            hipLaunchKernelGGL(conv1_moments_kernel, dim3(per_img, B), dim3(256), 0, st, feats, (float*)p.stats, 64, T, d.c1gx, d.c1gy);
-            hipLaunchKernelGGL(conv1_moments_reduce_kernel, dim3(C1_NMOM), dim3(256), 0, st, (const float*)p.stats, per_img * B, p.c1m);
-            hipLaunchKernelGGL(conv1_bn_from_moments_kernel, dim3(1), dim3(64), 0, st, (const double*)p.c1m, w->conv_w[0],
-                               (double)B * 64 * T, w->bn_w[0], w->bn_b[0], bn_running_mean[0], bn_running_var[0], bn_momentum,
-                               scale, shift, smean, sinv);
-        } else {
-        hipLaunchKernelGGL(conv1_stats_kernel, g1, dim3(256), 0, st, feats, w->conv_w[0], p.stats, 64, T);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(32), dim3(256), 0, st, (const float2*)p.stats, d.c1gx * d.c1gy * B, 32,
+        // conv1's BatchNorm statistics come from 54 moments of the INPUT (z_c = sum_t w_c[t] x_t: sums and sums of squares
+        // of z are bilinear in the taps), so conv1 itself runs once, fused with BN + ReLU + pool
+        const int tiles = d.c1gx * d.c1gy;
+        int per_img = (2048 + B - 1) / B;             // workgroups per image: >= 2048 in all when the batch allows it
+        per_img = per_img < 1 ? 1 : (per_img > tiles ? tiles : per_img);
+        hipLaunchKernelGGL(conv1_moments_kernel, dim3(per_img, B), dim3(256), 0, st, feats, (float*)p.stats, 64, T, d.c1gx, d.c1gy);
+        hipLaunchKernelGGL(conv1_moments_reduce_kernel, dim3(C1_NMOM), dim3(256), 0, st, (const float*)p.stats, per_img * B, p.c1m);
+        hipLaunchKernelGGL(conv1_bn_from_moments_kernel, dim3(1), dim3(64), 0, st, (const double*)p.c1m, w->conv_w[0],
                            (double)B * 64 * T, w->bn_w[0], w->bn_b[0], bn_running_mean[0], bn_running_var[0], bn_momentum,
                            scale, shift, smean, sinv);
-        }
-        hipLaunchKernelGGL(sir_conv1_mfma() ? conv1_mfma_bn_relu_pool_kernel : conv1_bn_relu_pool_kernel,
-                           dim3((d.wp1 + C1_PCOLS - 1) / C1_PCOLS, sir_conv1_mfma() ? 1 : d.c1gy, B), dim3(256), 0, st,
+        hipLaunchKernelGGL(conv1_mfma_bn_relu_pool_kernel, dim3((d.wp1 + C1_PCOLS - 1) / C1_PCOLS, 1, B), dim3(256), 0, st,
                            feats, w->conv_w[0], scale, shift, p.a1, 64, T, 32, d.wp1);
     }
     // conv2 block: raw conv + partial statistics on MFMA, finalize, BN+ReLU+pool
     {
-        constexpr size_t lds = conv_bf16x6_lds_bytes(4, 2);
         { SirProfScope prof(h, SIR_K_T_CONV2, st);
-        if (sir_conv_ns())
         hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 2, 0, 3>), dim3(d.c2gx, 1, B), dim3(256), conv_ns_lds_bytes(4, 2), st, (const float*)p.a1,
                            (const unsigned short*)p.wcb2, (const float*)nullptr, (const float*)nullptr, p.z2, 32, d.wp1, 16, d.wp2, p.stats);
-        else
-        hipLaunchKernelGGL((conv3x3_bf16x6_kernel<32, 64, 4, 2, 2, 2>), dim3(d.c2gx, 1, B), dim3(256), lds, st, (const float*)p.a1,
-                           (const unsigned short*)p.wcb2, (const float*)nullptr, (const float*)nullptr, p.z2, 32, d.wp1, 16, d.wp2, p.stats); }
+        }
         SirProfScope prof(h, SIR_K_T_BN2, st);
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, d.c2gx * B, 64,
                            (double)B * 32 * d.wp1, w->bn_w[1], w->bn_b[1], bn_running_mean[1], bn_running_var[1], bn_momentum,
@@ -289,16 +267,12 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
                            scale + 32, shift + 32, p.a2, B, 32, d.wp1, 64, 16, d.wp2);
     }
     {
-        constexpr size_t lds = conv_bf16x6_lds_bytes(2, 4);
         { SirProfScope prof(h, SIR_K_T_CONV3, st);
-        if (sir_conv_ns())
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 2, 0, 3>), dim3(d.c3fx, 1, B), dim3(256), conv_ns_lds_bytes(2, 2), st, (const float*)p.a2,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 2, 0, 4>), dim3(d.c3fx, 1, B), dim3(256), conv_ns_lds_bytes(2, 2), st, (const float*)p.a2,
                            (const unsigned short*)p.wcb3, (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats);
-        else
-        hipLaunchKernelGGL((conv3x3_bf16x6_kernel<64, 128, 2, 4, 2, 2>), dim3(d.c3gx, 1, B), dim3(256), lds, st, (const float*)p.a2,
-                           (const unsigned short*)p.wcb3, (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats); }
+        }
         SirProfScope prof(h, SIR_K_T_BN3, st);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, (sir_conv_ns() ? d.c3fx : d.c3gx) * B, 128,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, d.c3fx * B, 128,
                            (double)B * 16 * d.wp2, w->bn_w[2], w->bn_b[2], bn_running_mean[2], bn_running_var[2], bn_momentum,
                            scale + 96, shift + 96, smean + 96, sinv + 96);
         hipLaunchKernelGGL(bn_relu_pool_kernel<true>, dim3(grid_for((size_t)B * 8 * d.wp3 * 32)), dim3(256), 0, st, p.z3,
@@ -307,16 +281,13 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     KCHECK();
 
     const int M = B * S;
-    const dim3 ggrid(768 / GB_N, (M + GB_M - 1) / GB_M, 2);
     { SirProfScope prof(h, SIR_K_T_GEMM_IH0, st);
     hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, (const float*)p.x0, 1024, p.xs, (size_t)M, 1024);
-    SIR_HIP_TRY(launch_gemm_nt_bf16x6(st, sir_gemm_bf16x6_gen(), (const unsigned short*)p.xs, (const unsigned short*)p.wsl0,
+    SIR_HIP_TRY(launch_gemm_nt_bf16x6(h, st, (const unsigned short*)p.xs, (const unsigned short*)p.wsl0,
                        (const unsigned short*)(p.wsl0 + (size_t)3 * 768 * 1024), w->gru_b_ih[0], w->gru_b_ih[1], p.gi, 1536, M, 768, 1024)); }
     { SirProfScope prof(h, SIR_K_T_GRU0, st);
     if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
-    rc = sir_gru_variant() == 2
-             ? sir_launch_gru_quad(st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0, p.gxb, h->status)
-             : sir_launch_gru_pair(st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0, p.gxb, p.gfl, h->status);
+    rc = sir_launch_gru_quad(h, st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0, p.gxb);
     if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP; }
     if (rc != SIR_OK) return rc;
     const float* y0in = p.y0;
@@ -328,13 +299,11 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     }
     { SirProfScope prof(h, SIR_K_T_GEMM_IH1, st);
     hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, y0in, 512, p.xs, (size_t)M, 512);
-    SIR_HIP_TRY(launch_gemm_nt_bf16x6(st, sir_gemm_bf16x6_gen(), (const unsigned short*)p.xs, (const unsigned short*)p.wsl1,
+    SIR_HIP_TRY(launch_gemm_nt_bf16x6(h, st, (const unsigned short*)p.xs, (const unsigned short*)p.wsl1,
                        (const unsigned short*)(p.wsl1 + (size_t)3 * 768 * 512), w->gru_b_ih[2], w->gru_b_ih[3], p.gi, 1536, M, 768, 512)); }
     { SirProfScope prof(h, SIR_K_T_GRU1, st);
     if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
-    rc = sir_gru_variant() == 2
-             ? sir_launch_gru_quad(st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1, p.gxb, h->status)
-             : sir_launch_gru_pair(st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1, p.gxb, p.gfl, h->status);
+    rc = sir_launch_gru_quad(h, st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1, p.gxb);
     if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP; }
     if (rc != SIR_OK) return rc;
     SirProfScope prof_head(h, SIR_K_T_HEAD, st);
@@ -354,23 +323,6 @@ extern "C" int sir_ce_loss(sir_handle* h, const float* logits, const int64_t* la
     KCHECK();
     return SIR_OK;
 }
-
-namespace {
-
-// split-K "TN" product  out[M][N] = sum_k A[k][m] * B[k][n]  (slabs + deterministic reduce)
-void launch_tn(hipStream_t st, const TDims& d, const float* A, int lda, const float* Bm, int ldb, float* out, float* slab,
-               int M, int N, int K, int seq, int shift) {
-    const dim3 grid((N + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M, d.ksplits);
-    const size_t stride = (size_t)M * N;
-    float* dst = d.ksplits > 1 ? slab : out;
-    hipLaunchKernelGGL((gemm_general_kernel<true, true>), grid, dim3(256), 0, st, A, lda, Bm, (const float*)nullptr, 0, ldb, dst,
-                       N, stride, M, N, K, d.kchunk, seq, shift);
-    if (d.ksplits > 1)
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(stride)), dim3(256), 0, st, (const float*)slab, stride, d.ksplits,
-                           stride, out);
-}
-
-}  // namespace
 
 extern "C" int sir_model_train_bwd(sir_handle* h, const sir_model_weights* w, const float* feats, const float* dlogits,
                                    int batch, int t_frames, float dropout_p, uint64_t dropout_seed,
@@ -403,7 +355,6 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
     float* bsum_i = p.slab;                              // [B][1536] x2, consumed before the slabs are used
     float* bsum_h = p.slab + (size_t)B * 1536;
     const float* y0in = dropout_p > 0.0f ? p.y0d : p.y0;
-    const dim3 rgrid((B + GRU_BW - 1) / GRU_BW, 2);
 
     if (part != SIR_BWD_CNN) {
     // ---- head: fc + attention pooling ----------------------------------------------------
@@ -413,7 +364,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                        p.dy1, daw_part, dab_part, S, C);
     hipLaunchKernelGGL(colsum_kernel, dim3(8), dim3(256), 0, st, (const float*)daw_part, B, 512, 512, g->attn_w);
     hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, st, (const float*)dab_part, B, 1, 1, g->attn_b); }
-    KCHECK();                                          // (W_hh re-layout p.wr4: train_prep_kernel of the forward)
+    KCHECK();
 
     // ---- GRU layers, top down ----------------------------------------------------------------
     for (int layer = 1; layer >= 0; --layer) {
@@ -422,28 +373,23 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         const float* yout = layer ? p.y1 : p.y0;
         const float* xin = layer ? y0in : p.x0;
         const int in_sz = layer ? 512 : 1024;
-static const int gru_bwd_variant = getenv("SIR_GRU_BWD_VARIANT") ? atoi(getenv("SIR_GRU_BWD_VARIANT")) : 1;
         { SirProfScope prof(h, layer ? SIR_K_B_GRU1 : SIR_K_B_GRU0, st);
-        if (gru_bwd_variant == 1) {
-            if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
-            rc = sir_launch_gru_bwd_pair(st, dy, gates, yout, w->gru_w_hh[2 * layer], w->gru_w_hh[2 * layer + 1], p.dgi, p.dgh, bsum_i, bsum_h,
-                                         B, S, p.gxb, h->status);
-            if (rc != SIR_OK) return rc;
-            if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP;
-        } else
-        hipLaunchKernelGGL(gru_bwd_kernel, dim3((B + GRU_BBW - 1) / GRU_BBW, 2), dim3(1024), 0, st, dy, gates, yout, (const float*)(p.wr4 + (size_t)2 * layer * 768 * 256),
-                           p.dgi, p.dgh, bsum_i, bsum_h, B, S);
+        if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
+        rc = sir_launch_gru_bwd_pair(h, st, dy, gates, yout, w->gru_w_hh[2 * layer], w->gru_w_hh[2 * layer + 1], p.dgi, p.dgh, bsum_i, bsum_h,
+                                     B, S, p.gxb);
+        if (rc != SIR_OK) return rc;
+        if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP;
         // bias gradients first: bsum_* alias the slab area used below
         hipLaunchKernelGGL(gru_bias_colsum_kernel, dim3(24, 2), dim3(256), 0, st, (const float*)bsum_i, (const float*)bsum_h, B,
                            g->gru_b_ih[2 * layer], g->gru_b_ih[2 * layer + 1], g->gru_b_hh[2 * layer], g->gru_b_hh[2 * layer + 1]); }
         { SirProfScope prof(h, layer ? SIR_K_B_DW1 : SIR_K_B_DW0, st);
-        static const int tn_x6 = getenv("SIR_GEMM_TN_X6") ? atoi(getenv("SIR_GEMM_TN_X6")) : 1;
-        if (tn_x6) {
+        {
             // all four weight-gradient GEMMs of the layer (2 directions x {W_ih, W_hh}) in one bf16x6 launch
-            static bool tn_attr = false;
-            if (!tn_attr) {
+            if (!h->attr_tn) {
                 SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
-                tn_attr = true;
+                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
+                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES_64));
+                h->attr_tn = true;
             }
             TnJobs jb{};
             float* outs[4];
@@ -478,25 +424,12 @@ static const int gru_bwd_variant = getenv("SIR_GRU_BWD_VARIANT") ? atoi(getenv("
             SlabJobs sj{};
             for (int j = 0; j < 4; ++j) { sj.src[j] = jb.slab[j]; sj.out[j] = outs[j]; sj.n[j] = sizes[j]; }
             hipLaunchKernelGGL(slab_reduce_jobs_kernel, dim3(grid_for(sizes[0]), 4), dim3(256), 0, st, sj, nsplit);
-        } else
-        for (int dir = 0; dir < 2; ++dir) {
-            const int gi_idx = 2 * layer + dir;
-            launch_tn(st, d, p.dgi + dir * 768, 1536, xin, in_sz, g->gru_w_ih[gi_idx], p.slab, 768, in_sz, M, 0, 0);
-            launch_tn(st, d, p.dgh + dir * 768, 1536, yout + dir * 256, 512, g->gru_w_hh[gi_idx], p.slab, 768, 256, M, S,
-                      dir ? 1 : -1);
         }
         }
         // gradient wrt the layer input: dgi [M][1536] x [W_ih; W_ih_reverse] [1536][in]
         SirProfScope prof(h, layer ? SIR_K_B_DX1 : SIR_K_B_DX0, st);
         float* dxin = layer ? p.dy0 : p.dx0;
-static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6")) : 1;
-        if (nn_x6) {
-            static bool nn_attr = false;
-            if (!nn_attr) {
-                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
-                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES_64));
-                nn_attr = true;
-            }
+        {
             TnJobs jn{};
             jn.njobs = 1;
             jn.A[0] = p.dgi; jn.lda[0] = 1536;
@@ -514,10 +447,7 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
                 jn.tile0[1] = ntiles;
                 hipLaunchKernelGGL(gemm_tn_bf16x6_kernel<false>, dim3(ntiles, 1), dim3(512), TN_LDS_BYTES, st, jn, M, 1536, 1536, 1);
             }
-        } else
-        hipLaunchKernelGGL((gemm_general_kernel<false, true>), dim3((in_sz + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M, 1), dim3(256), 0, st,
-                           (const float*)p.dgi, 1536, w->gru_w_ih[2 * layer], w->gru_w_ih[2 * layer + 1], 768, in_sz, dxin, in_sz,
-                           (size_t)0, M, in_sz, 1536, 1536, 0, 0);
+        }
         if (layer == 1 && dropout_p > 0.0f)
             hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for((size_t)M * 512)), dim3(256), 0, st, p.dy0, (size_t)M * 512,
                                dropout_p, (unsigned long long)dropout_seed);
@@ -527,69 +457,46 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
     if (part == SIR_BWD_HEAD_GRU) return SIR_OK;
 
     // ---- conv3 block -------------------------------------------------------------------------
+    if (!h->attr_wgrad) {
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<64, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        h->attr_wgrad = true;
+    }
     {
-        const int ppb = 64;
-        const size_t npix = (size_t)B * 8 * d.wp3;
-        const int nblk = (int)((npix + ppb - 1) / ppb);
-        int nfin = nblk;
-        { SirProfScope prof(h, SIR_K_B_BN3, st);
-        if (bn_reduce_pooled) {                       // from the pooled activations x0 (GRU layout) instead of z3
-            const int rows = B * d.wp3, rpb = 16;
-            nfin = (rows + rpb - 1) / rpb;
+        // BatchNorm backward sums from the POOLED activations x0 (GRU layout) and their gradient -- dy = da wherever a > 0 and
+        // xhat at the routed maximum is (a - beta) / gamma -- instead of the four times larger raw conv output z3
+        const int rows = B * d.wp3, rpb = 16, nfin = (rows + rpb - 1) / rpb;
+        {
+            SirProfScope prof(h, SIR_K_B_BN3, st);
             hipLaunchKernelGGL(bn_bwd_reduce_pooled_gru_kernel, dim3(nfin), dim3(256), 0, st, (const float*)p.x0, (const float*)p.dx0,
                                (const float*)p.z3, w->bn_w[2], w->bn_b[2], scale + 96, shift + 96, smean + 96, sinv + 96, p.stats, rows,
                                16, d.wp2, d.wp3, rpb);
-        } else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, st, (const float*)p.z3, (const float*)p.dx0,
-                           scale + 96, shift + 96, smean + 96, sinv + 96, p.stats, B, 16, d.wp2, 128, 8, d.wp3, ppb);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, nfin, 128,
-                           (double)B * 16 * d.wp2, g->bn_w[2], g->bn_b[2], mdy + 96, mdyx + 96);
-        hipLaunchKernelGGL(bn_bwd_dz_kernel<true>, dim3(grid_for((size_t)B * 8 * ((d.wp2 + 1) / 2) * 32)), dim3(256), 0, st, (const float*)p.z3,
-                           (const float*)p.dx0, scale + 96, shift + 96, smean + 96, sinv + 96, mdy + 96, mdyx + 96, p.dz3, B, 16,
-                           d.wp2, 128, 8, d.wp3); }
-        const int Wk = (d.wp2 + 1) & ~1;
-        const size_t lds = ((size_t)Wk * 128 + 3 * (size_t)(Wk + 2) * 64) * 4;
-        static bool attr3 = false;
-        if (!attr3) {
-            SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_mfma_kernel<64, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr3 = true;
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, nfin, 128,
+                               (double)B * 16 * d.wp2, g->bn_w[2], g->bn_b[2], mdy + 96, mdyx + 96);
+            hipLaunchKernelGGL(bn_bwd_dz_kernel<true>, dim3(grid_for((size_t)B * 8 * ((d.wp2 + 1) / 2) * 32)), dim3(256), 0, st, (const float*)p.z3,
+                               (const float*)p.dx0, scale + 96, shift + 96, smean + 96, sinv + 96, mdy + 96, mdyx + 96, p.dz3, B, 16,
+                               d.wp2, 128, 8, d.wp3);
         }
-        if (lds > 160 * 1024) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
-        static const int wgrad_x6 = getenv("SIR_WGRAD_X6") ? atoi(getenv("SIR_WGRAD_X6")) : 1;
-        int nslab3 = d.wg3_blocks;
-        { SirProfScope prof(h, SIR_K_B_WGRAD3, st);
-        if (wgrad_x6) {
-            static bool attrx = false;
-            if (!attrx) {
-                SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<64, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attrx = true;
-            }
+        {
+            SirProfScope prof(h, SIR_K_B_WGRAD3, st);
             const size_t ldsx = wgrad_x6_lds_bytes(64, 128, d.wp2);
-            if (ldsx > 160 * 1024 || d.wp2 > wgrad_x6_max_w(128)) { sir_set_error("sir_model_train_bwd: t_frames too large for the bf16x6 weight-gradient tile"); return SIR_EUNSUPPORTED; }
-            nslab3 = d.wg3_blocks * wgrad_x6_ksplit(64, 128);
+            if (ldsx > 160 * 1024 || d.wp2 > wgrad_x6_max_w(128)) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
+            const int nslab3 = d.wg3_blocks * wgrad_x6_ksplit(64, 128);
             hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<64, 128>), dim3(d.wg3_blocks), dim3(512), ldsx, st, (const float*)p.dz3,
                                (const float*)p.a2, p.slab, 16, d.wp2, d.wg3_rb);
-        } else
-        hipLaunchKernelGGL((conv_wgrad_mfma_kernel<64, 128>), dim3(d.wg3_blocks), dim3(576), lds, st, (const float*)p.dz3,
-                           (const float*)p.a2, p.slab, 16, d.wp2, d.wg3_rb);
-        {
             float* part = p.slab + (size_t)nslab3 * 9 * 128 * 64;
             hipLaunchKernelGGL(wgrad_reduce_partial_kernel, dim3((9 * 128 * 64 / 4 + 255) / 256, WGR_PARTS), dim3(256), 0, st,
                                (const float*)p.slab, nslab3, 9 * 128 * 64 / 4, part);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 128 * 64 + 255) / 256), dim3(256), 0, st, (const float*)part, WGR_PARTS, 64, 128,
                                g->conv_w[2]);
-        } }
-        SirProfScope prof(h, SIR_K_B_DGRAD3, st);
-        // (data-gradient weights p.wcb3t: train_prep_kernel of the forward)
-        constexpr size_t ldsd = conv_bf16x6_lds_bytes(2, 4);
-        if (sir_conv_ns())
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<128, 64, 2, 4, 2, 0, 3>), dim3(d.c3gx, 1, B), dim3(256), conv_ns_lds_bytes(2, 4), st, (const float*)p.dz3,
-                           (const unsigned short*)p.wcb3t, (const float*)nullptr, (const float*)nullptr, p.da2, 16, d.wp2, 8, d.wp3,
-                           (float2*)nullptr);
-        else
-        hipLaunchKernelGGL((conv3x3_bf16x6_kernel<128, 64, 2, 4, 2, 2>), dim3(d.c3gx, 1, B), dim3(256), ldsd, st, (const float*)p.dz3,
-                           (const unsigned short*)p.wcb3t, (const float*)nullptr, (const float*)nullptr, p.da2, 16, d.wp2, 8, d.wp3,
-                           (float2*)nullptr);
+        }
+        {
+            // data gradient = the forward kernel on the flipped / transposed prepared weights p.wcb3t (train_prep_kernel of the forward)
+            SirProfScope prof(h, SIR_K_B_DGRAD3, st);
+            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<128, 64, 2, 4, 2, 0, 4>), dim3(d.c3gx, 1, B), dim3(256), conv_ns_lds_bytes(2, 4), st,
+                               (const float*)p.dz3, (const unsigned short*)p.wcb3t, (const float*)nullptr, (const float*)nullptr, p.da2, 16, d.wp2,
+                               8, d.wp3, (float2*)nullptr);
+        }
         KCHECK();
     }
     // ---- conv2 block -------------------------------------------------------------------------
@@ -597,93 +504,54 @@ static const int nn_x6 = getenv("SIR_GEMM_NN_X6") ? atoi(getenv("SIR_GEMM_NN_X6"
         const int ppb = 64;
         const size_t npix = (size_t)B * 16 * d.wp2;
         const int nblk = (int)((npix + ppb - 1) / ppb);
-        { SirProfScope prof(h, SIR_K_B_BN2, st);
-        if (bn_reduce_pooled)
-        hipLaunchKernelGGL(bn_bwd_reduce_pooled_kernel, dim3(nblk), dim3(256), 0, st, (const float*)p.a2, (const float*)p.da2,
-                           (const float*)p.z2, w->bn_w[1], w->bn_b[1], scale + 32, shift + 32, smean + 32, sinv + 32, p.stats, B, 32,
-                           d.wp1, 64, 16, d.wp2, ppb);
-        else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, st, (const float*)p.z2, (const float*)p.da2,
-                           scale + 32, shift + 32, smean + 32, sinv + 32, p.stats, B, 32, d.wp1, 64, 16, d.wp2, ppb);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, nblk, 64,
-                           (double)B * 32 * d.wp1, g->bn_w[1], g->bn_b[1], mdy + 32, mdyx + 32);
-        hipLaunchKernelGGL(bn_bwd_dz_kernel<false>, dim3(grid_for((size_t)B * 16 * ((d.wp1 + 1) / 2) * 16)), dim3(256), 0, st, (const float*)p.z2,
-                           (const float*)p.da2, scale + 32, shift + 32, smean + 32, sinv + 32, mdy + 32, mdyx + 32, p.dz2, B, 32,
-                           d.wp1, 64, 16, d.wp2); }
-        const int Wk = (d.wp1 + 1) & ~1;
-        const size_t lds = ((size_t)Wk * 64 + 3 * (size_t)(Wk + 2) * 32) * 4;
-        static bool attr2 = false;
-        if (!attr2) {
-            SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_mfma_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr2 = true;
+        {
+            SirProfScope prof(h, SIR_K_B_BN2, st);
+            hipLaunchKernelGGL(bn_bwd_reduce_pooled_kernel, dim3(nblk), dim3(256), 0, st, (const float*)p.a2, (const float*)p.da2,
+                               (const float*)p.z2, w->bn_w[1], w->bn_b[1], scale + 32, shift + 32, smean + 32, sinv + 32, p.stats, B, 32,
+                               d.wp1, 64, 16, d.wp2, ppb);
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, nblk, 64,
+                               (double)B * 32 * d.wp1, g->bn_w[1], g->bn_b[1], mdy + 32, mdyx + 32);
+            hipLaunchKernelGGL(bn_bwd_dz_kernel<false>, dim3(grid_for((size_t)B * 16 * ((d.wp1 + 1) / 2) * 16)), dim3(256), 0, st, (const float*)p.z2,
+                               (const float*)p.da2, scale + 32, shift + 32, smean + 32, sinv + 32, mdy + 32, mdyx + 32, p.dz2, B, 32,
+                               d.wp1, 64, 16, d.wp2);
         }
-        if (lds > 160 * 1024) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
-        static const int wgrad_x6b = getenv("SIR_WGRAD_X6") ? atoi(getenv("SIR_WGRAD_X6")) : 1;
-        int nslab2 = d.wg2_blocks;
-        { SirProfScope prof(h, SIR_K_B_WGRAD2, st);
-        if (wgrad_x6b) {
-            static bool attrx2 = false;
-            if (!attrx2) {
-                SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attrx2 = true;
-            }
+        {
+            SirProfScope prof(h, SIR_K_B_WGRAD2, st);
             const size_t ldsx = wgrad_x6_lds_bytes(32, 64, d.wp1);
-            if (ldsx > 160 * 1024 || d.wp1 > wgrad_x6_max_w(64)) { sir_set_error("sir_model_train_bwd: t_frames too large for the bf16x6 weight-gradient tile"); return SIR_EUNSUPPORTED; }
-            nslab2 = d.wg2_blocks * wgrad_x6_ksplit(32, 64);
+            if (ldsx > 160 * 1024 || d.wp1 > wgrad_x6_max_w(64)) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
+            const int nslab2 = d.wg2_blocks * wgrad_x6_ksplit(32, 64);
             hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<32, 64>), dim3(d.wg2_blocks), dim3(512), ldsx, st, (const float*)p.dz2,
                                (const float*)p.a1, p.slab, 32, d.wp1, d.wg2_rb);
-        } else
-        hipLaunchKernelGGL((conv_wgrad_mfma_kernel<32, 64>), dim3(d.wg2_blocks), dim3(576), lds, st, (const float*)p.dz2,
-                           (const float*)p.a1, p.slab, 32, d.wp1, d.wg2_rb);
-        {
             float* part = p.slab + (size_t)nslab2 * 9 * 64 * 32;
             hipLaunchKernelGGL(wgrad_reduce_partial_kernel, dim3((9 * 64 * 32 / 4 + 255) / 256, WGR_PARTS), dim3(256), 0, st,
                                (const float*)p.slab, nslab2, 9 * 64 * 32 / 4, part);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 32 + 255) / 256), dim3(256), 0, st, (const float*)part, WGR_PARTS, 32, 64,
                                g->conv_w[1]);
-        } }
-        SirProfScope prof(h, SIR_K_B_DGRAD2, st);
-        // (data-gradient weights p.wcb2t: train_prep_kernel of the forward)
-        constexpr size_t ldsd = conv_bf16x6_lds_bytes(4, 2);
-        if (sir_conv_ns())
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 32, 4, 2, 2, 0, 3>), dim3(d.c2gx, 1, B), dim3(256), conv_ns_lds_bytes(4, 2), st, (const float*)p.dz2,
-                           (const unsigned short*)p.wcb2t, (const float*)nullptr, (const float*)nullptr, p.da1, 32, d.wp1, 16, d.wp2,
-                           (float2*)nullptr);
-        else
-        hipLaunchKernelGGL((conv3x3_bf16x6_kernel<64, 32, 4, 2, 2, 2>), dim3(d.c2gx, 1, B), dim3(256), ldsd, st, (const float*)p.dz2,
-                           (const unsigned short*)p.wcb2t, (const float*)nullptr, (const float*)nullptr, p.da1, 32, d.wp1, 16, d.wp2,
-                           (float2*)nullptr);
+        }
+        {
+            SirProfScope prof(h, SIR_K_B_DGRAD2, st);
+            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 32, 4, 2, 2, 0, 4>), dim3(d.c2gx, 1, B), dim3(256), conv_ns_lds_bytes(4, 2), st,
+                               (const float*)p.dz2, (const unsigned short*)p.wcb2t, (const float*)nullptr, (const float*)nullptr, p.da1, 32, d.wp1,
+                               16, d.wp2, (float2*)nullptr);
+        }
         KCHECK();
     }
-    // ---- conv1 block (recomputed) ------------------------------------------------------------
+    // ---- conv1 block ------------------------------------------------------------------------
     {
+        // ONE recompute pass: (sum dy, sum dy*xhat, sum dy*x_tap) per channel; the mean terms of dz = s (dy - m1 - xhat m2) and
+        // with them the rest of dW1 are closed forms in the input moments of the forward (conv1_bwd_finalize_kernel, in double)
         SirProfScope prof(h, SIR_K_B_CONV1, st);
         const dim3 g1(d.c1gx, d.c1gy, B);
         const int nblk = d.c1gx * d.c1gy * B;
-        if (conv1_moments) {
-            // one recompute pass: (sum dy, sum dy*xhat, sum dy*x_tap) per channel; the rest of dW1 is closed form in the moments
-            hipLaunchKernelGGL(conv1_bwd_kernel<2>, g1, dim3(256), 0, st, feats, w->conv_w[0], (const float*)p.da1, scale, shift,
-                               smean, sinv, (const float*)nullptr, (const float*)nullptr, c1part, 64, T, 32, d.wp1);
-            float* c1tmp = (float*)p.stats;           // [128][352] partial column sums, then [352] totals behind them
-            float* c1tot = c1tmp + 128 * 352;
-            hipLaunchKernelGGL(colsum_partial_kernel, dim3((352 + 63) / 64, 128), dim3(256), 0, st, (const float*)c1part, nblk, 352,
-                               352, c1tmp);
-            hipLaunchKernelGGL(colsum_kernel, dim3((352 + 63) / 64), dim3(256), 0, st, (const float*)c1tmp, 128, 352, 352, c1tot);
-            hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(320), 0, st, (const float*)c1tot, (const double*)p.c1m,
-                               w->conv_w[0], scale, smean, sinv, (double)B * 64 * T, g->bn_w[0], g->bn_b[0], g->conv_w[0]);
-            KCHECK();
-            return SIR_OK;
-        }
-        hipLaunchKernelGGL(conv1_bwd_kernel<0>, g1, dim3(256), 0, st, feats, w->conv_w[0], (const float*)p.da1, scale, shift,
-                           smean, sinv, (const float*)nullptr, (const float*)nullptr, (float*)p.stats, 64, T, 32, d.wp1);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(32), dim3(256), 0, st, (const float2*)p.stats, nblk, 32, (double)B * 64 * T,
-                           g->bn_w[0], g->bn_b[0], mdy, mdyx);
-        hipLaunchKernelGGL(conv1_bwd_kernel<1>, g1, dim3(256), 0, st, feats, w->conv_w[0], (const float*)p.da1, scale, shift,
-                           smean, sinv, (const float*)mdy, (const float*)mdyx, c1part, 64, T, 32, d.wp1);
-        float* c1tmp = (float*)p.stats;               // [128][288], the BN partials are consumed by now
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3((288 + 63) / 64, 128), dim3(256), 0, st, (const float*)c1part, nblk, 288,
-                           288, c1tmp);
-        hipLaunchKernelGGL(colsum_kernel, dim3((288 + 63) / 64), dim3(256), 0, st, (const float*)c1tmp, 128, 288, 288, g->conv_w[0]);
+        hipLaunchKernelGGL(conv1_bwd_kernel<2>, g1, dim3(256), 0, st, feats, w->conv_w[0], (const float*)p.da1, scale, shift,
+                           smean, sinv, (const float*)nullptr, (const float*)nullptr, c1part, 64, T, 32, d.wp1);
+        float* c1tmp = (float*)p.stats;           // [128][352] partial column sums, then [352] totals behind them
+        float* c1tot = c1tmp + 128 * 352;
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((352 + 63) / 64, 128), dim3(256), 0, st, (const float*)c1part, nblk, 352,
+                           352, c1tmp);
+        hipLaunchKernelGGL(colsum_kernel, dim3((352 + 63) / 64), dim3(256), 0, st, (const float*)c1tmp, 128, 352, 352, c1tot);
+        hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(320), 0, st, (const float*)c1tot, (const double*)p.c1m,
+                           w->conv_w[0], scale, smean, sinv, (double)B * 64 * T, g->bn_w[0], g->bn_b[0], g->conv_w[0]);
         KCHECK();
     }
     return SIR_OK;

@@ -68,6 +68,9 @@ struct sir_handle {
     hipEvent_t cluster_done;
     hipStream_t cluster_stream;
     bool cluster_pending;
+    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) latches, per handle = per device (a process-wide static would skip
+    // the second device of a process that drives several)
+    bool attr_gemm_v3, attr_gru_quad, attr_gru_bwd, attr_tn, attr_wgrad;
 };
 
 // bracket of a cluster-kernel launch (see sir_handle::cluster_done)
@@ -118,31 +121,18 @@ static inline size_t sir_align_up(size_t x, size_t a) { return (x + a - 1) / a *
 // model_train.hip
 size_t sir_train_workspace_bytes_impl(int batch, int t_frames);
 
-// gru_pair.hip
-size_t sir_gru_pair_xbuf_bytes(int batch);
-size_t sir_gru_pair_flag_bytes(int batch);
-int sir_launch_gru_pair(hipStream_t st, bool save, const float* gi, const float* whh0, const float* whh1, const float* bhh0,
-                        const float* bhh1, float* y, int B, int S, float* gates, float* xbuf, unsigned int* flags, unsigned int* status);
-
 // features.hip
 int sir_features_launch(sir_handle* h, const void* wave, int wave_dtype, int64_t wave_stride,
                         const int32_t* lengths, int batch, int max_len, float* out, int t_pad,
                         float* db_out, void* workspace, size_t workspace_bytes, const sir_augment* aug,
                         hipStream_t stream);
 
-// generation of the bf16x6 input-projection GEMM (SIR_GEMM_BF16X6_GEN, default 2 = LDS-DMA kernel; 1 = first kernel)
-int sir_gemm_bf16x6_gen();
-// quad-workgroup MFMA GRU recurrence (gru_quad.hip); SIR_GRU_VARIANT=2 selects it
-size_t sir_gru_quad_xbuf_bytes(int batch);
-int sir_launch_gru_quad(hipStream_t st, bool save, const float* gi, const float* whh0, const float* whh1, const float* bhh0,
-                        const float* bhh1, float* y, int B, int S, float* gates, float* xbuf, unsigned int* status,
+// GRU recurrences (gru_quad.hip: forward, clusters of four workgroups on the matrix cores; gru_pair.hip: BPTT, pairs of
+// workgroups).  Both write h->status if an exchange spin times out.
+size_t sir_gru_xbuf_bytes(int batch);          // exchange-granule workspace: the larger of the two kernels' needs
+int sir_launch_gru_quad(sir_handle* h, hipStream_t st, bool save, const float* gi, const float* whh0, const float* whh1, const float* bhh0,
+                        const float* bhh1, float* y, int B, int S, float* gates, float* xbuf,
                         unsigned short* yplanes = nullptr, const void* wfrag0 = nullptr, const void* wfrag1 = nullptr);
 void sir_prep_whh_quad(hipStream_t st, const float* whh, void* frag);     // -> 768 * 256 * 6 bytes
-int sir_gru_variant();
-// paired-workgroup GRU backward recurrence (gru_pair.hip); SIR_GRU_BWD_VARIANT=0 selects the streaming kernel
-int sir_launch_gru_bwd_pair(hipStream_t st, const float* dy, const float* gates, const float* y, const float* whh0, const float* whh1,
-                            float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S, float* xbuf, unsigned int* status);
-// conv1 on the f32 matrix pipe (SIR_CONV1_MFMA, default 1) instead of the direct VALU form
-int sir_conv1_mfma();
-// convolution generation (SIR_CONV_NS, default 1 = output channels split over the waves)
-int sir_conv_ns();
+int sir_launch_gru_bwd_pair(sir_handle* h, hipStream_t st, const float* dy, const float* gates, const float* y, const float* whh0,
+                            const float* whh1, float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S, float* xbuf);

@@ -8,59 +8,6 @@
 // BatchNorm with batch statistics
 // ------------------------------------------------------------------------------------------
 
-// conv1 is recomputed instead of stored (9 MACs per output): this pass only accumulates the
-// per-channel (sum, sum of squares) of the raw conv1 output over a 8 x 64 pixel tile.
-static __global__ __launch_bounds__(256) void conv1_stats_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           float2* __restrict__ stats, int H, int W) {
-    __shared__ float tile[C1_TR * C1_TC];
-    __shared__ float red[8 * 32 * 2];
-    const int b = blockIdx.z, py0 = blockIdx.y * C1_PROWS, px0 = blockIdx.x * C1_PCOLS;
-    const int tid = threadIdx.x, c = tid & 31, slot = tid >> 5;
-    const float* xb = x + (size_t)b * H * W;
-    for (int i = tid; i < C1_TR * C1_TC; i += 256) {
-        const int ty = i / C1_TC, tx = i - ty * C1_TC;
-        const int gy = 2 * py0 - 1 + ty, gx = 2 * px0 - 1 + tx;
-        tile[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xb[(size_t)gy * W + gx] : 0.0f;
-    }
-    float wk[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
-    __syncthreads();
-    float s = 0.0f, q = 0.0f;
-    for (int i = 0; i < (C1_PROWS * C1_PCOLS) / 8; ++i) {
-        const int pp = slot + 8 * i, pyl = pp / C1_PCOLS, pxl = pp % C1_PCOLS;
-        float in[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) in[r][k] = tile[(2 * pyl + r) * C1_TC + 2 * pxl + k];
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                const int gy = 2 * (py0 + pyl) + dy, gx = 2 * (px0 + pxl) + dx;
-                if (gy >= H || gx >= W) continue;
-                float a = 0.0f;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) a = fmaf(in[dy + ky][dx + kx], wk[ky * 3 + kx], a);
-                s += a;
-                q = fmaf(a, a, q);
-            }
-    }
-    red[(slot * 32 + c) * 2] = s;
-    red[(slot * 32 + c) * 2 + 1] = q;
-    __syncthreads();
-    if (tid < 32) {
-        float ts = 0.0f, tq = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { ts += red[(k * 32 + tid) * 2]; tq += red[(k * 32 + tid) * 2 + 1]; }
-        const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        stats[blk * 32 + tid] = make_float2(ts, tq);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // conv1 BatchNorm statistics WITHOUT computing conv1: z_c = sum_t w_c[t] x_t with x_t the nine shifted copies of the
 // (zero-padded) feature image, hence
@@ -479,9 +426,6 @@ __device__ __forceinline__ void prep_whh_bwd_elem(const float* __restrict__ w, f
     const int e = idx & 3, k = (idx >> 2) & 255, r4 = idx >> 10;
     wr4[idx] = w[(size_t)(r4 * 4 + e) * 256 + k];
 }
-static __global__ void prep_whh_bwd_kernel(const float* __restrict__ w, float* __restrict__ wr4) {
-    prep_whh_bwd_elem(w, wr4, blockIdx.x * blockDim.x + threadIdx.x);
-}
 
 // Every per-step re-layout of the weights (they change with each optimizer step) in ONE launch: a dozen ~5 us launches
 // otherwise.  kind 0: split3_rows (a = ld_in = K, b = rows), 1: prep_conv_w_bf16x3 (a = cin, b = cout),
@@ -523,231 +467,6 @@ static __global__ void slab_reduce_jobs_kernel(SlabJobs jobs, int nslab) {
 }
 
 constexpr int GRU_BBW = 4;      // utterances per workgroup of the backward recurrence
-static __global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ gates,
-                                                        const float* __restrict__ y, const float* __restrict__ wr4,
-                                                        float* __restrict__ dgi, float* __restrict__ dgh,
-                                                        float* __restrict__ bsum_i, float* __restrict__ bsum_h, int B,
-                                                        int S) {
-    // bsum_i / bsum_h [B][1536]: per-utterance sums over time of dgi / dgh (bias gradients are their
-    // column sums over B rows instead of B*S rows)
-    __shared__ __attribute__((aligned(16))) float gsh[GRU_BBW * 768];       // dgh[b][row]
-    __shared__ float ps[4 * GRU_BBW * GRU_H];                               // partial[rs][b][k]
-    const int dir = blockIdx.y, b0 = blockIdx.x * GRU_BBW;
-    const int tid = threadIdx.x, u = tid & 255, ks = tid >> 8;
-    const int bme = ks;
-    const bool bvalid = (b0 + bme) < B;
-    const float4* w4 = reinterpret_cast<const float4*>(wr4) + (size_t)dir * 192 * 256;
-    float dh_carry = 0.0f;
-    float sum_r = 0.f, sum_z = 0.f, sum_n = 0.f, sum_nr = 0.f;
-    for (int step = S - 1; step >= 0; --step) {
-        const int t = dir ? (S - 1 - step) : step;                // time index processed at `step`
-        const int tp = dir ? t + 1 : t - 1;                       // where h_prev lives (invalid at step 0)
-        float drp = 0.f, dzp = 0.f, dnp = 0.f, dnr = 0.f, dhz = 0.f;
-        if (bvalid) {
-            const size_t row = (size_t)(b0 + bme) * S + t;
-            const float* gs = gates + (row * 2 + dir) * 1024;
-            const float r = gs[u], zg = gs[256 + u], nn = gs[512 + u], hn = gs[768 + u];
-            const float hprev = (step > 0) ? y[((size_t)(b0 + bme) * S + tp) * 512 + dir * 256 + u] : 0.0f;
-            const float dh = dy[row * 512 + dir * 256 + u] + dh_carry;
-            const float dn = dh * (1.0f - zg);
-            const float dz = dh * (hprev - nn);
-            dnp = dn * (1.0f - nn * nn);
-            drp = dnp * hn * r * (1.0f - r);
-            dzp = dz * zg * (1.0f - zg);
-            dnr = dnp * r;
-            dhz = dh * zg;
-            float* gi_o = dgi + row * 1536 + dir * 768;
-            float* gh_o = dgh + row * 1536 + dir * 768;
-            gi_o[u] = drp; gi_o[256 + u] = dzp; gi_o[512 + u] = dnp;
-            gh_o[u] = drp; gh_o[256 + u] = dzp; gh_o[512 + u] = dnr;
-            sum_r += drp; sum_z += dzp; sum_n += dnp; sum_nr += dnr;
-        }
-        gsh[bme * 768 + u] = drp; gsh[bme * 768 + 256 + u] = dzp; gsh[bme * 768 + 512 + u] = dnr;
-        __syncthreads();
-        float acc[GRU_BBW];
-#pragma unroll
-        for (int bb = 0; bb < GRU_BBW; ++bb) acc[bb] = 0.0f;
-#pragma unroll 4
-        for (int r4 = ks * 48; r4 < ks * 48 + 48; ++r4) {
-            const float4 wv = w4[(size_t)r4 * 256 + u];
-#pragma unroll
-            for (int bb = 0; bb < GRU_BBW; ++bb) {
-                const float4 g4 = *reinterpret_cast<const float4*>(gsh + bb * 768 + r4 * 4);
-                acc[bb] = fmaf(wv.x, g4.x, acc[bb]); acc[bb] = fmaf(wv.y, g4.y, acc[bb]);
-                acc[bb] = fmaf(wv.z, g4.z, acc[bb]); acc[bb] = fmaf(wv.w, g4.w, acc[bb]);
-            }
-        }
-#pragma unroll
-        for (int bb = 0; bb < GRU_BBW; ++bb) ps[(ks * GRU_BBW + bb) * GRU_H + u] = acc[bb];
-        __syncthreads();
-        dh_carry = dhz + ps[(0 * GRU_BBW + bme) * GRU_H + u] + ps[(1 * GRU_BBW + bme) * GRU_H + u] +
-                   ps[(2 * GRU_BBW + bme) * GRU_H + u] + ps[(3 * GRU_BBW + bme) * GRU_H + u];
-        __syncthreads();
-    }
-    if (bvalid) {
-        float* bi = bsum_i + (size_t)(b0 + bme) * 1536 + dir * 768;
-        float* bh = bsum_h + (size_t)(b0 + bme) * 1536 + dir * 768;
-        bi[u] = sum_r; bi[256 + u] = sum_z; bi[512 + u] = sum_n;
-        bh[u] = sum_r; bh[256 + u] = sum_z; bh[512 + u] = sum_nr;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// General fp32-MFMA GEMM for the backward pass.
-//   C[m][n] (+)= sum_k opA(m,k) * opB(k,n)
-//   A_KM = false: A is [M][lda] (k contiguous)      true: A is [K][lda] (m contiguous)
-//   B_KN = false: B is [N][ldb] (k contiguous)      true: B is [K][ldb] (n contiguous)
-//   split-K over blockIdx.z: slab z covers k in [z*kchunk, (z+1)*kchunk) and is written to
-//   C + z*slab_stride (deterministic partial slabs, summed by slab_reduce_kernel), or, with
-//   gridDim.z == 1, directly to C.
-//   B2/ksplit: rows k >= ksplit of a k-major B come from B2 (two stacked weight matrices).
-//   seq/shift (B_KN only): row k of B is taken from row k+shift of the same length-`seq` sequence,
-//   zero outside it (the h_{t-1} / h_{t+1} operand of the W_hh gradient).
-// 128 x 64 tile, BK = 32, 4 waves 2x2, wave tile 64 x 32.
-// ------------------------------------------------------------------------------------------
-template <bool A_KM, bool B_KN>
-__global__ __launch_bounds__(256) void gemm_general_kernel(const float* __restrict__ A, int lda,
-                                                            const float* __restrict__ B, const float* __restrict__ B2,
-                                                            int ksplit, int ldb, float* __restrict__ C, int ldc,
-                                                            size_t slab_stride, int M, int N, int K, int kchunk, int seq,
-                                                            int shift) {
-    constexpr int SA = A_KM ? (GB_M + 4) : GB_S;         // LDS row stride of the A tile
-    constexpr int SB = B_KN ? (GB_N + 4) : GB_S;
-    __shared__ __attribute__((aligned(16))) float As[A_KM ? GB_K * SA : GB_M * SA];
-    __shared__ __attribute__((aligned(16))) float Bs[B_KN ? GB_K * SB : GB_N * SB];
-    const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
-    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv >> 1, wn = wv & 1, m = lane & 31, kh = lane >> 5;
-
-    float4 ra[4], rb[2];
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            if (!A_KM) {
-                const int row = idx >> 3, c4 = idx & 7;          // [128 m][8 x float4 of k]
-                const int k = k0 + c4 * 4;
-                ra[i] = (m0 + row < M && k < kend) ? *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * lda + k)
-                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                const int kr = idx >> 5, c4 = idx & 31;          // [32 k][32 x float4 of m]
-                const int k = k0 + kr, mm = m0 + c4 * 4;
-                ra[i] = (k < kend && mm < M) ? *reinterpret_cast<const float4*>(A + (size_t)k * lda + mm)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            if (!B_KN) {
-                const int row = idx >> 3, c4 = idx & 7;          // [64 n][8 x float4 of k]
-                const int k = k0 + c4 * 4;
-                rb[i] = (n0 + row < N && k < kend) ? *reinterpret_cast<const float4*>(B + (size_t)(n0 + row) * ldb + k)
-                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                const int kr = idx >> 4, c4 = idx & 15;          // [32 k][16 x float4 of n]
-                int k = k0 + kr;
-                const int nn = n0 + c4 * 4;
-                bool ok = k < kend && nn < N;
-                const float* src = B;
-                if (seq > 0) {
-                    const int t = k % seq + shift;
-                    ok = ok && t >= 0 && t < seq;
-                    k += shift;
-                } else if (B2 && k >= ksplit) {
-                    src = B2;
-                    k -= ksplit;
-                }
-                rb[i] = ok ? *reinterpret_cast<const float4*>(src + (size_t)k * ldb + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            if (!A_KM) *reinterpret_cast<float4*>(As + (idx >> 3) * SA + (idx & 7) * 4) = ra[i];
-            else *reinterpret_cast<float4*>(As + (idx >> 5) * SA + (idx & 31) * 4) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            if (!B_KN) *reinterpret_cast<float4*>(Bs + (idx >> 3) * SB + (idx & 7) * 4) = rb[i];
-            else *reinterpret_cast<float4*>(Bs + (idx >> 4) * SB + (idx & 15) * 4) = rb[i];
-        }
-    };
-
-    f32x16 acc[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
-
-    if (kbeg < kend) {
-        load_tile(kbeg);
-        store_tile();
-        __syncthreads();
-        for (int k0 = kbeg; k0 < kend; k0 += GB_K) {
-            const bool more = k0 + GB_K < kend;
-            if (more) load_tile(k0 + GB_K);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                float a0[4], a1[4], bq[4];
-                if (!A_KM) {
-                    const float4 v0 = *reinterpret_cast<const float4*>(As + (wm * 64 + m) * SA + kk * 8 + kh * 4);
-                    const float4 v1 = *reinterpret_cast<const float4*>(As + (wm * 64 + 32 + m) * SA + kk * 8 + kh * 4);
-                    a0[0] = v0.x; a0[1] = v0.y; a0[2] = v0.z; a0[3] = v0.w;
-                    a1[0] = v1.x; a1[1] = v1.y; a1[2] = v1.z; a1[3] = v1.w;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        a0[i] = As[(kk * 8 + kh * 4 + i) * SA + wm * 64 + m];
-                        a1[i] = As[(kk * 8 + kh * 4 + i) * SA + wm * 64 + 32 + m];
-                    }
-                }
-                if (!B_KN) {
-                    const float4 v = *reinterpret_cast<const float4*>(Bs + (wn * 32 + m) * SB + kk * 8 + kh * 4);
-                    bq[0] = v.x; bq[1] = v.y; bq[2] = v.z; bq[3] = v.w;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) bq[i] = Bs[(kk * 8 + kh * 4 + i) * SB + wn * 32 + m];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], bq[i], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], bq[i], acc[1], 0, 0, 0);
-                }
-            }
-            __syncthreads();
-            if (more) {
-                store_tile();
-                __syncthreads();
-            }
-        }
-    }
-    float* Cz = C + (size_t)blockIdx.z * slab_stride;
-    const int n = n0 + wn * 32 + m;
-    if (n < N) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < M) Cz[(size_t)row * ldc + n] = acc[mt][r];
-            }
-    }
-}
-
-// out[i] = sum_z slabs[z][i]
-static __global__ void slab_reduce_kernel(const float* __restrict__ slabs, size_t slab_stride, int nslab, size_t n,
-                                   float* __restrict__ out) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float a = 0.0f;
-        for (int z = 0; z < nslab; ++z) a += slabs[(size_t)z * slab_stride + i];
-        out[i] = a;
-    }
-}
 
 // a[i] += b[i]  /  a[i] = a[i]*mask  helpers for the layer-0 dropout backward
 static __global__ void dropout_bwd_kernel(float* __restrict__ g, size_t n, float p, unsigned long long seed) {
@@ -779,63 +498,6 @@ __device__ __forceinline__ float route1(float y00, float y01, float y10, float y
     if (y10 > best) { best = y10; arg = 2; }
     if (y11 > best) { best = y11; arg = 3; }
     return (arg == pos && best > 0.0f) ? g : 0.0f;
-}
-
-template <bool GRU_IN>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ z, const float* __restrict__ da,
-                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                             float2* __restrict__ part, int B, int H, int W, int C, int Hp,
-                                                             int Wp, int pix_per_block) {
-    // block = (channel group of 64 lanes x 4 pixel lanes); loops over `pix_per_block` pooled pixels
-    __shared__ float rs[256], rq[256];
-    const int c4n = C / 4;                                // float4 groups per pixel
-    const int lanes_c = c4n < 64 ? c4n : 64;              // threads along channels
-    const int pl = 256 / lanes_c;                         // pixel lanes
-    const int c4 = threadIdx.x % lanes_c, pslot = threadIdx.x / lanes_c;
-    const size_t npix = (size_t)B * Hp * Wp;
-    const size_t p0 = (size_t)blockIdx.x * pix_per_block;
-    float4 sdy = make_float4(0.f, 0.f, 0.f, 0.f), sdx = sdy;
-    for (int cc = c4; cc < c4n; cc += lanes_c) {
-        const float4 s = *reinterpret_cast<const float4*>(scale + cc * 4), t = *reinterpret_cast<const float4*>(shift + cc * 4);
-        const float4 mu = *reinterpret_cast<const float4*>(mean + cc * 4), is = *reinterpret_cast<const float4*>(invstd + cc * 4);
-        for (int i = pslot; i < pix_per_block; i += pl) {
-            const size_t p = p0 + i;
-            if (p >= npix) break;
-            const int px = p % Wp, py = (p / Wp) % Hp, b = p / ((size_t)Wp * Hp);
-            const float4 g = load_da4<GRU_IN>(da, b, py, px, cc, Hp, Wp, C);
-            float4 zz[4], yy[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                zz[q] = *reinterpret_cast<const float4*>(z + (((size_t)b * H + 2 * py + (q >> 1)) * W + 2 * px + (q & 1)) * C + cc * 4);
-                yy[q] = make_float4(fmaf(zz[q].x, s.x, t.x), fmaf(zz[q].y, s.y, t.y), fmaf(zz[q].z, s.z, t.z), fmaf(zz[q].w, s.w, t.w));
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float dx_ = route1(yy[0].x, yy[1].x, yy[2].x, yy[3].x, q, g.x);
-                const float dy_ = route1(yy[0].y, yy[1].y, yy[2].y, yy[3].y, q, g.y);
-                const float dz_ = route1(yy[0].z, yy[1].z, yy[2].z, yy[3].z, q, g.z);
-                const float dw_ = route1(yy[0].w, yy[1].w, yy[2].w, yy[3].w, q, g.w);
-                sdy.x += dx_; sdy.y += dy_; sdy.z += dz_; sdy.w += dw_;
-                sdx.x = fmaf(dx_, (zz[q].x - mu.x) * is.x, sdx.x); sdx.y = fmaf(dy_, (zz[q].y - mu.y) * is.y, sdx.y);
-                sdx.z = fmaf(dz_, (zz[q].z - mu.z) * is.z, sdx.z); sdx.w = fmaf(dw_, (zz[q].w - mu.w) * is.w, sdx.w);
-            }
-        }
-        // reduce over the pixel lanes for this channel group, component by component
-        const float vs[4] = {sdy.x, sdy.y, sdy.z, sdy.w}, vq[4] = {sdx.x, sdx.y, sdx.z, sdx.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            __syncthreads();
-            rs[threadIdx.x] = vs[e]; rq[threadIdx.x] = vq[e];
-            __syncthreads();
-            if (pslot == 0) {
-                float a = 0.0f, q2 = 0.0f;
-                for (int k = 0; k < pl; ++k) { a += rs[k * lanes_c + c4]; q2 += rq[k * lanes_c + c4]; }
-                part[(size_t)blockIdx.x * C + cc * 4 + e] = make_float2(a, q2);
-            }
-        }
-        sdy = make_float4(0.f, 0.f, 0.f, 0.f); sdx = sdy;
-    }
 }
 
 // The same two sums from the POOLED activations a = pool(relu(bn(z))): dy = da wherever a > 0 (the window's maximum passed
@@ -1166,107 +828,6 @@ static __global__ void conv1_bwd_finalize_kernel(const float* __restrict__ total
     const double xhx = (double)invstd[c] * (zx - (double)mean[c] * M[tap]);
     dw[c * 9 + tap] = (float)((double)scale[c] * (A - m1 * M[tap] - m2 * xhx));
     if (tap == 0) { dbeta[c] = (float)sdy; dgamma[c] = (float)sdx; }
-}
-
-// ------------------------------------------------------------------------------------------
-// data-gradient weights: the dgrad of a 3x3/pad-1 conv is the same conv with the roles of the
-// channel axes swapped and the taps flipped.  Output in the wp[g][co'][8] format of
-// prep_conv_w_kernel, where co' runs over the forward INPUT channels and the 8-group over the
-// forward OUTPUT channels.
-// ------------------------------------------------------------------------------------------
-static __global__ void prep_conv_wT_kernel(const float* __restrict__ w, float* __restrict__ wp, int cin_f, int cout_f) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = cin_f * 9 * cout_f;
-    if (idx >= total) return;
-    const int e = idx & 7, cop = (idx >> 3) % cin_f, g = (idx >> 3) / cin_f;
-    const int co_f = (g / 9) * 8 + e, tap = 8 - (g % 9);
-    wp[idx] = w[((size_t)co_f * cin_f + cop) * 9 + tap];
-}
-
-// ------------------------------------------------------------------------------------------
-// conv weight gradient on fp32 MFMA:  dW[co][ci][ky][kx] = sum_{b,y,x} dz[b][y][x][co] * a[b][y+ky-1][x+kx-1][ci]
-//   GEMM view: M = co, N = ci (per tap), K = pixels.  576 threads = 9 waves, wave = tap.
-//   One workgroup walks RB consecutive rows of one image: the dz row and a 3-row ring of the input
-//   (zero halo) sit in LDS; A operand = dz[pixel][co] and B operand = a[pixel+tap][ci] are both
-//   read with conflict-free ds_read_b32 (32 consecutive channels).  Per-workgroup partial
-//   gradients go to slab[blk][tap][co][ci] and are summed (and transposed to the torch layout) by
-//   wgrad_reduce_kernel: deterministic, no atomics.
-//   (Tried: dealing the 9 * MT * NT tiles of a k step evenly to 8 / 4 waves instead of wave = tap, to balance the
-//   SIMDs -- 9 waves put three on one SIMD.  Correct but 10 % slower: one more ds_read_b32 per MFMA; the kernel is
-//   bound by its LDS operand reads, not by the matrix pipes.)
-// ------------------------------------------------------------------------------------------
-template <int CIN, int COUT>
-__global__ __launch_bounds__(576) void conv_wgrad_mfma_kernel(const float* __restrict__ dz, const float* __restrict__ a,
-                                                               float* __restrict__ slab, int H, int W, int RB) {
-    constexpr int MT = COUT / 32, NT = CIN / 32;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int Wk = (W + 1) & ~1;                 // pixels per row rounded up to a k-pair
-    float* dzs = lds;                            // [Wk][COUT]
-    float* as_ = lds + (size_t)Wk * COUT;        // [3][Wk + 2][CIN]
-    const int arow = (Wk + 2) * CIN;
-    const int blocks_per_img = H / RB;
-    const int b = blockIdx.x / blocks_per_img, y0 = (blockIdx.x % blocks_per_img) * RB;
-    const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6;
-    const int ky = tap / 3, kx = tap % 3;
-    const int m = lane & 31, kh = lane >> 5;
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
-
-    auto load_a_row = [&](int y) {               // input row y -> ring slot (y+1)%3, zero halo / out of range
-        float* dst = as_ + ((y + 1) % 3) * arow;
-        const bool valid = (y >= 0 && y < H);
-        const float* src = a + (((size_t)b * H + (valid ? y : 0)) * W) * CIN;
-        for (int i = tid; i < (Wk + 2) * (CIN / 4); i += 576) {
-            const int px = i / (CIN / 4), c4 = i % (CIN / 4);
-            const int gx = px - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid && gx >= 0 && gx < W) v = *reinterpret_cast<const float4*>(src + (size_t)gx * CIN + c4 * 4);
-            *reinterpret_cast<float4*>(dst + px * CIN + c4 * 4) = v;
-        }
-    };
-    load_a_row(y0 - 1);
-    load_a_row(y0);
-    for (int y = y0; y < y0 + RB; ++y) {
-        __syncthreads();                          // previous row fully consumed
-        load_a_row(y + 1);
-        const float* zsrc = dz + (((size_t)b * H + y) * W) * COUT;
-        for (int i = tid; i < Wk * (COUT / 4); i += 576) {
-            const int px = i / (COUT / 4), c4 = i % (COUT / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (px < W) v = *reinterpret_cast<const float4*>(zsrc + (size_t)px * COUT + c4 * 4);
-            *reinterpret_cast<float4*>(dzs + px * COUT + c4 * 4) = v;
-        }
-        __syncthreads();
-        const float* arow_p = as_ + ((y + ky) % 3) * arow;        // input row y + ky - 1 lives in slot (y+ky)%3
-        for (int s = 0; s < Wk / 2; ++s) {
-            const int px = 2 * s + kh;
-            float av[MT], bv[NT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[mt] = dzs[px * COUT + mt * 32 + m];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = arow_p[(px + kx) * CIN + nt * 32 + m];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
-        }
-    }
-    float* o = slab + ((size_t)blockIdx.x * 9 + tap) * COUT * CIN;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                o[(size_t)co * CIN + nt * 32 + m] = acc[mt][nt][r];
-            }
 }
 
 // dW[co][ci][tap] = sum_blk slab[blk][tap][co][ci], in two ordered (deterministic) passes: WGR_PARTS partial sums over

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <vector>
 #include "../csrc/bf16x6_kernels.h"
+#include "../tools/legacy_kernels.h"
 
 #define CK_(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -51,8 +52,9 @@ static void run(const char* name, int B, int H, int W) {
     float t1 = time_us(st, reps, [&] {
         hipLaunchKernelGGL((conv3x3_bf16x6_kernel<CIN, COUT, PR, PC, OUT_MODE, (PR * PC) / 4>), grid, dim3(256), lds, st, (const float*)dx, (const unsigned short*)wpb,
                            (const float*)ds, (const float*)dt, o1, H, W, Hp, Wp, (float2*)nullptr); });
+    constexpr size_t lds_ns = conv_ns_lds_bytes(PR, PC);       // the product kernel's half-major, unpadded LDS image
     float t2 = time_us(st, reps, [&] {
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 0>), grid, dim3(256), lds, st, (const float*)dx, (const unsigned short*)wpb,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 0>), grid, dim3(256), lds_ns, st, (const float*)dx, (const unsigned short*)wpb,
                            (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
     CK_(hipStreamSynchronize(st));
     std::vector<float> h1(nout), h2(nout);
@@ -63,28 +65,24 @@ static void run(const char* name, int B, int H, int W) {
     printf("  gen1 (pixels split over waves)   %8.1f us  %7.1f TF\n", t1, gf * 1e3 / t1);
     printf("  gen2 (channels split over waves) %8.1f us  %7.1f TF   max |gen1 - gen2| = %.3e (max |out| %.2f)\n", t2, gf * 1e3 / t2, d, mx);
     float t3 = time_us(st, reps, [&] {
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 1>), grid, dim3(256), lds, st, (const float*)dx, (const unsigned short*)wpb,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 1>), grid, dim3(256), lds_ns, st, (const float*)dx, (const unsigned short*)wpb,
                            (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
     float t4 = time_us(st, reps, [&] {
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 2>), grid, dim3(256), lds, st, (const float*)dx, (const unsigned short*)wpb,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 2>), grid, dim3(256), lds_ns, st, (const float*)dx, (const unsigned short*)wpb,
                            (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
     float t5 = time_us(st, reps, [&] {
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 3>), grid, dim3(256), lds, st, (const float*)dx, (const unsigned short*)wpb,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 3>), grid, dim3(256), lds_ns, st, (const float*)dx, (const unsigned short*)wpb,
                            (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
     float t6 = time_us(st, reps, [&] {
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 0, 3>), grid, dim3(256), lds, st, (const float*)dx, (const unsigned short*)wpb,
-                           (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
-    constexpr size_t lds_np = (size_t)3 * (8 * PR + 2) * (4 * PC + 2) * 48;
-    float t7 = time_us(st, reps, [&] {
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 0, 3, false>), grid, dim3(256), lds_np, st, (const float*)dx, (const unsigned short*)wpb,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 0, 3>), grid, dim3(256), lds_ns, st, (const float*)dx, (const unsigned short*)wpb,
                            (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
     if (PR * PC <= 4 || COUT <= 64) {
         float t8 = time_us(st, reps, [&] {
-            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 0, 4, false>), grid, dim3(256), lds_np, st, (const float*)dx, (const unsigned short*)wpb,
+            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 0, 4>), grid, dim3(256), lds_ns, st, (const float*)dx, (const unsigned short*)wpb,
                                (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
-        printf("  gen2 with launch_bounds(256,4), unpadded rows: %.1f us\n", t8);
+        printf("  gen2 with launch_bounds(256,4): %.1f us\n", t8);
     }
-    printf("  gen2 with launch_bounds(256,3): %.1f us (LDS %zu B);  + unpadded rows: %.1f us (LDS %zu B)\n", t6, lds, t7, lds_np);
+    printf("  gen2 with launch_bounds(256,3): %.1f us (LDS %zu B)\n", t6, lds_ns);
     printf("  gen2 knock-outs (timing only): weights once %.1f us, tile staged once %.1f us, both %.1f us\n", t3, t4, t5);
     hipFree(dx); hipFree(dw); hipFree(ds); hipFree(dt); hipFree(o1); hipFree(o2); hipFree(wpb);
 }

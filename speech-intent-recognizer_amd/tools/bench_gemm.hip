@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <vector>
 #include "../csrc/bf16x6_kernels.h"
+#include "../tools/legacy_kernels.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
 
