@@ -369,9 +369,10 @@ def main():
     pool = [device_clips(batch, CLIP_LEN, 1234 + 1000 * rank + i, dev) for i in range(N_POOL)]
     lengths = torch.full((batch,), CLIP_LEN, dtype=torch.int32, device=dev)
     preds = [None]
-    # batch pipelining (sir_amd/pipeline.py): consecutive batches alternate over `--streams` HIP streams, each with
-    # its own feature buffer, feature workspace and model workspace (weights shared), so that the latency-bound
-    # GRU recurrence of one batch overlaps the matrix-core-bound convolutions of the next
+    # batch pipelining INSIDE the library (sir_pipeline, include/sir_hip.h; sir_amd/pipeline.py wraps it): this process
+    # stays on ONE stream; the library alternates consecutive batches over `--streams` streams of its own, each with its
+    # own feature buffer and model workspace (weights shared), so that the latency-bound GRU recurrence of one batch
+    # overlaps the matrix-core-bound convolutions of the next
     from sir_amd.pipeline import BatchPipeline
     ns = max(1, args.streams)
     pipe = BatchPipeline(model, n_streams=ns)
@@ -439,7 +440,9 @@ def main():
     if rank == 0:
         log(f"timed {args.repeats} x {args.steps} steps: median {elapsed:.4f} s")
     dom_ms, dom_cnt = collect()
-    # reference leg: the same regions on ONE stream (no batch pipelining), dominant kernel timed in isolation
+    # reference leg: the same regions strictly serial (sir_pipeline with one slot = the caller's stream), dominant kernel
+    # timed in isolation.  (A single batch cannot be made to overlap with itself: all its utterances already advance in
+    # parallel inside the recurrence, so any split only lengthens the dependent chain -- DESIGN.md section 4.)
     single = None
     if ns > 1:
         pipe1 = BatchPipeline(model, n_streams=1)
@@ -576,7 +579,7 @@ def main():
                                    "resident in HBM -> 64-mel log-mel [64,200] -> CNNAudioGRU(31) forward -> argmax",
                        "batch_per_gpu": batch, "clip_samples": CLIP_LEN, "n_mels": 64, "frames": T_PAD,
                        "num_classes": NUM_CLASSES, "parallelism": f"utterance-sharded x{world}, no data-path collective",
-                       "streams_per_gpu": ns,
+                       "streams_per_gpu": ns, "pipelining": "library-owned (sir_pipeline): the caller uses one stream",
                        "share_gpu_rehearsal": share_gpu,
                        "arithmetic": "fp32 accuracy end to end: contractions as bf16x6 (three-way bf16 split of both operands, six "
                                      "v_mfma_f32_32x32x16_bf16 products, f32 accumulation), everything else fp32 VALU"},

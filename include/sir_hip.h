@@ -169,6 +169,28 @@ int sir_model_infer(sir_handle* h, const sir_model_weights* w, const float* feat
  * .cpu()) or per epoch (scripts/train.py:116's loss.item()); sir_profile_collect performs the same check. */
 int sir_check_status(sir_handle* h, void* stream);
 
+/* ---- cross-batch pipelining (owned by the library) ------------------------------------------------
+ * One batch's kernels run back to back on one stream, and some of them cannot fill the chip on their own: the GRU
+ * recurrence is a chain of S dependent steps that occupies half of the CUs at a fraction of their matrix throughput
+ * (all utterances of the batch already advance in parallel inside it, so splitting a batch does not shorten the chain --
+ * DESIGN.md section 4).  What hides it is the NEXT batch's convolutions.  A sir_pipeline owns n_slots HIP streams and the
+ * events that order them against the caller's stream, so that a caller living on ONE stream gets the overlap:
+ *     sir_pipeline_begin(p, caller_stream, &slot, &slot_stream)   -- slot = submission count mod n_slots; its stream now
+ *                                                                    waits for everything queued on caller_stream
+ *     sir_features_fwd(..., slot_stream); sir_model_infer(..., slot_stream);   (buffers / workspace of THAT slot)
+ *     sir_pipeline_end(p, slot)                                   -- marks the slot's work complete-able
+ *     ... more batches ...
+ *     sir_pipeline_join(p, caller_stream)                         -- caller_stream waits for every slot (no host sync)
+ * A slot's buffers are reused n_slots submissions later (same stream: ordered); the caller reads results on
+ * caller_stream after the join.  n_slots = 1 degenerates to the caller's own stream.  Results are bit-identical to the
+ * single-stream order.  Replaces nothing in the reference (its evaluate loop is serial, scripts/evaluate.py:79-86). */
+typedef struct sir_pipeline sir_pipeline;
+int sir_pipeline_create(sir_handle* h, int n_slots, sir_pipeline** out);     /* 1 <= n_slots <= 4 */
+int sir_pipeline_destroy(sir_pipeline* p);
+int sir_pipeline_begin(sir_pipeline* p, void* caller_stream, int* slot, void** slot_stream);
+int sir_pipeline_end(sir_pipeline* p, int slot);
+int sir_pipeline_join(sir_pipeline* p, void* caller_stream);
+
 /* ---- training step ----------------------------------------------------------------------------
  * Replaces the body of train_epoch (scripts/train.py:90-107): model(mel) in train() mode,
  * criterion(output, label), loss.backward(), optimizer.step().

@@ -66,6 +66,11 @@ SIGNATURES = {
     "sir_model_infer": (C.c_int, [C.c_void_p, C.POINTER(ModelWeights), C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sir_check_status": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sir_pipeline_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "sir_pipeline_destroy": (C.c_int, [C.c_void_p]),
+    "sir_pipeline_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "sir_pipeline_end": (C.c_int, [C.c_void_p, C.c_int]),
+    "sir_pipeline_join": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sir_model_train_fwd": (C.c_int, [C.c_void_p, C.POINTER(ModelWeights), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                       C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p,
                                       C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -154,6 +154,80 @@ extern "C" int sir_model_set_weights_version(sir_handle* h, uint64_t version) {
     return SIR_OK;
 }
 
+// ---- cross-batch pipelining ---------------------------------------------------------------------
+struct sir_pipeline {
+    sir_handle* h;
+    int n;
+    unsigned long long seq;
+    hipStream_t st[4];
+    hipEvent_t ready[4], done[4];
+    bool open[4], used[4];
+    hipStream_t caller[4];
+};
+
+extern "C" int sir_pipeline_create(sir_handle* h, int n_slots, sir_pipeline** out) {
+    if (!h || !out || n_slots < 1 || n_slots > 4) { sir_set_error("sir_pipeline_create: bad argument (1 <= n_slots <= 4)"); return SIR_EINVAL; }
+    sir_pipeline* p = new sir_pipeline();
+    p->h = h; p->n = n_slots; p->seq = 0;
+    for (int i = 0; i < 4; ++i) { p->st[i] = nullptr; p->ready[i] = p->done[i] = nullptr; p->open[i] = p->used[i] = false; p->caller[i] = nullptr; }
+    if (n_slots > 1)
+        for (int i = 0; i < n_slots; ++i) {
+            if (hipStreamCreateWithFlags(&p->st[i], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&p->ready[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&p->done[i], hipEventDisableTiming) != hipSuccess) {
+                sir_set_error("sir_pipeline_create: stream / event creation failed");
+                sir_pipeline_destroy(p);
+                return SIR_EHIP;
+            }
+        }
+    *out = p;
+    return SIR_OK;
+}
+
+extern "C" int sir_pipeline_destroy(sir_pipeline* p) {
+    if (!p) return SIR_OK;
+    for (int i = 0; i < 4; ++i) {
+        if (p->st[i]) { (void)hipStreamSynchronize(p->st[i]); (void)hipStreamDestroy(p->st[i]); }
+        if (p->ready[i]) (void)hipEventDestroy(p->ready[i]);
+        if (p->done[i]) (void)hipEventDestroy(p->done[i]);
+    }
+    delete p;
+    return SIR_OK;
+}
+
+extern "C" int sir_pipeline_begin(sir_pipeline* p, void* caller_stream, int* slot, void** slot_stream) {
+    if (!p || !slot || !slot_stream) { sir_set_error("sir_pipeline_begin: NULL argument"); return SIR_EINVAL; }
+    const int k = (int)(p->seq % (unsigned long long)p->n);
+    if (p->open[k]) { sir_set_error("sir_pipeline_begin: slot %d is still open (sir_pipeline_end missing)", k); return SIR_EINVAL; }
+    hipStream_t cs = (hipStream_t)caller_stream;
+    if (p->n == 1) {
+        *slot_stream = caller_stream;
+    } else {
+        SIR_HIP_TRY(hipEventRecord(p->ready[k], cs));            // inputs (and earlier reads of this slot's outputs) on the caller's stream
+        SIR_HIP_TRY(hipStreamWaitEvent(p->st[k], p->ready[k], 0));
+        *slot_stream = (void*)p->st[k];
+    }
+    p->open[k] = true; p->caller[k] = cs;
+    *slot = k;
+    ++p->seq;
+    return SIR_OK;
+}
+
+extern "C" int sir_pipeline_end(sir_pipeline* p, int slot) {
+    if (!p || slot < 0 || slot >= p->n || !p->open[slot]) { sir_set_error("sir_pipeline_end: slot %d is not open", slot); return SIR_EINVAL; }
+    if (p->n > 1) SIR_HIP_TRY(hipEventRecord(p->done[slot], p->st[slot]));
+    p->open[slot] = false; p->used[slot] = true;
+    return SIR_OK;
+}
+
+extern "C" int sir_pipeline_join(sir_pipeline* p, void* caller_stream) {
+    if (!p) { sir_set_error("sir_pipeline_join: NULL pipeline"); return SIR_EINVAL; }
+    if (p->n > 1)
+        for (int k = 0; k < p->n; ++k)
+            if (p->used[k]) SIR_HIP_TRY(hipStreamWaitEvent((hipStream_t)caller_stream, p->done[k], 0));
+    return SIR_OK;
+}
+
 // ---- event profiling ------------------------------------------------------------------------
 static const char* const kKernelNames[SIR_K_COUNT] = {
     "feat_frames", "feat_normalise", "weight_prep", "conv1_bn_relu_pool", "conv2_mfma_bn_relu_pool",

@@ -1,65 +1,120 @@
-"""Batch pipelining over HIP streams.
+"""Batch pipelining over HIP streams (torch-side wrapper of the library's ``sir_pipeline``).
 
 The kernels of one batch run back to back on one stream; some of them cannot fill the GPU on their own (the GRU
 recurrence is a chain of 25 dependent steps per layer and occupies half of the CUs at a fraction of their
-matrix throughput).  Independent batches therefore alternate over a few streams, each with its OWN feature buffer,
-feature workspace and model workspace (weights are shared, read-only): the recurrence of batch i overlaps the
-convolutions of batch i+1.  Results are bit-identical to the single-stream path -- only the launch order across
-batches changes.  Measured on MI355X at batch 256: 306 k -> 385 k utterances/s with two streams.
+matrix throughput).  Independent batches therefore alternate over a few library-owned streams, each with its OWN
+feature buffer and model workspace (weights are shared, read-only): the recurrence of batch i overlaps the
+convolutions of batch i+1, while the caller stays on ONE stream.  Results are bit-identical to the single-stream
+path -- only the launch order across batches changes.  Measured on MI355X at batch 256: 337 k -> 410 k utterances/s.
 """
 import torch
 
 from . import _native, ops
-from .featurizer import HipFeaturizer, get_featurizer
+from .featurizer import HipFeaturizer, get_featurizer  # noqa: F401
+
+
+# sir_pipeline objects per (device, n_slots), kept for the life of the process: torch's caching allocator remembers every
+# stream a tensor was record_stream()-ed on and records an event there when the tensor is freed -- a slot stream destroyed
+# before that (e.g. when a BatchPipeline is garbage-collected) would be used after free at interpreter exit.
+_pipelines = {}
+
+
+def _library_pipeline(n):
+    import ctypes as C
+    key = (torch.cuda.current_device(), n)
+    if key not in _pipelines:
+        p = C.c_void_p()
+        _native.check(_native.lib().sir_pipeline_create(get_featurizer().handle, n, C.byref(p)), "sir_pipeline_create")
+        _pipelines[key] = (p, {})          # handle, raw hipStream_t -> torch ExternalStream
+    return _pipelines[key]
 
 
 class BatchPipeline:
-    """``n_streams`` slots; ``infer(i, feats)`` / ``features(i, wave, ...)`` run batch ``i`` on slot ``i % n``.
+    """``n_streams`` slots over ``sir_pipeline`` (the LIBRARY owns the slot streams and the events that order them against
+    the caller's stream -- include/sir_hip.h; this class only wraps those streams for torch's allocator and keeps one
+    model workspace per slot).  ``features(i, wave, ...)`` / ``infer(i, feats)`` run batch ``i`` on the slot the library
+    hands out for it; calls that carry the same ``i`` share a slot.
 
-    Outputs of a slot are valid after ``synchronize()`` (or after the slot's stream has been waited on); a slot's
-    buffers are reused ``n_streams`` batches later, so consume or copy results before that."""
+    Outputs of a slot are valid on the caller's stream after ``join()`` (or on the host after ``synchronize()``); a slot's
+    buffers are reused ``n_streams`` batches later, so consume or copy results before that.  Results are bit-identical
+    to the single-stream order."""
 
     def __init__(self, model, n_streams=2):
         _native.require_hip()
         self.model = model
         self.n = max(1, int(n_streams))
-        self._launch = torch.cuda.current_stream()
-        # with one slot everything stays on the caller's stream; otherwise every slot gets its own stream and only
-        # waits for the caller's stream (where the inputs are produced), never for another slot
-        self.streams = [self._launch] if self.n == 1 else [torch.cuda.Stream() for _ in range(self.n)]
-        self.featurizers = [get_featurizer()] + [HipFeaturizer() for _ in range(self.n - 1)]
+        self._lib = _native.lib()
+        self._p, self._ext = _library_pipeline(self.n)
+        self.featurizer = get_featurizer()
         self.workspaces = [model._ws] + [ops.Workspace() for _ in range(self.n - 1)]
+        self._cur = None                   # (batch index, slot, torch stream) of the open submission
+
+    def __del__(self):
+        try:
+            self._end()                    # never leave a slot of the shared library pipeline open
+        except Exception:
+            pass
+
+    @property
+    def streams(self):
+        return list(self._ext.values())
+
+    def _begin(self, i):
+        """Open (or continue) the submission of batch ``i`` -> (slot, torch stream)."""
+        import ctypes as C
+        if self._cur is not None and self._cur[0] == i:
+            return self._cur[1], self._cur[2]
+        self._end()
+        slot, raw = C.c_int(), C.c_void_p()
+        _native.check(self._lib.sir_pipeline_begin(self._p, _native.current_stream_ptr(), C.byref(slot), C.byref(raw)),
+                      "sir_pipeline_begin")
+        if self.n == 1:
+            st = torch.cuda.current_stream()
+        else:
+            st = self._ext.get(raw.value)
+            if st is None:
+                st = self._ext[raw.value] = torch.cuda.ExternalStream(raw.value)
+        self._cur = (i, slot.value, st)
+        return slot.value, st
+
+    def _end(self):
+        if self._cur is not None:
+            _native.check(self._lib.sir_pipeline_end(self._p, self._cur[1]), "sir_pipeline_end")
+            self._cur = None
 
     def slot(self, i):
-        return i % self.n
+        """Slot of batch ``i`` (opens its submission): index of the per-slot buffers the caller should hand over."""
+        return self._begin(i)[0]
 
     def features(self, i, wave, lengths=None, **kw):
-        k = self.slot(i)
+        k, st = self._begin(i)
         if self.n > 1:
-            self.streams[k].wait_stream(self._launch)       # inputs produced on the caller's stream
-            wave.record_stream(self.streams[k])             # ... and must outlive the slot's kernels
-        with torch.cuda.stream(self.streams[k]):
-            return self.featurizers[k](wave, lengths, **kw)
+            wave.record_stream(st)                          # must outlive the slot's kernels
+            if lengths is not None:
+                lengths.record_stream(st)
+        with torch.cuda.stream(st):
+            return self.featurizer(wave, lengths, **kw)
 
     @torch.no_grad()
     def infer(self, i, feats, want_argmax=True):
-        """eval-mode forward (+ argmax) of batch ``i`` on its slot's stream."""
-        k = self.slot(i)
+        """eval-mode forward (+ argmax) of batch ``i`` on its slot's stream; closes the submission of batch ``i``."""
+        k, st = self._begin(i)
         if self.n > 1:
-            self.streams[k].wait_stream(self._launch)
-            feats.record_stream(self.streams[k])
-        with torch.cuda.stream(self.streams[k]):
-            return ops.model_infer(self.model, feats, self.workspaces[k], want_argmax=want_argmax)
+            feats.record_stream(st)
+        with torch.cuda.stream(st):
+            out = ops.model_infer(self.model, feats, self.workspaces[k], want_argmax=want_argmax)
+        self._end()
+        return out
 
     def synchronize(self):
-        for s in self.streams:
-            s.synchronize()
+        self._end()
+        self.join()
+        torch.cuda.current_stream().synchronize()
 
     def join(self):
         """Make the caller's stream wait for every slot (no host synchronisation)."""
-        if self.n > 1:
-            for s in self.streams:
-                self._launch.wait_stream(s)
+        self._end()
+        _native.check(self._lib.sir_pipeline_join(self._p, _native.current_stream_ptr()), "sir_pipeline_join")
 
 
 class FeaturePrefetcher:

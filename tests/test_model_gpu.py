@@ -123,6 +123,45 @@ def test_batch_pipeline_matches_single_stream(sd):
         assert torch.equal(l0, l1) and torch.equal(a0, a1)
 
 
+def test_library_pipeline_from_one_caller_stream(sd):
+    """sir_pipeline (include/sir_hip.h): the LIBRARY owns the slot streams; a caller that stays on one stream, feeds raw
+    waveforms and only joins at the end gets bit-identical features / logits / argmax for 1, 2 and 3 slots, and can consume
+    the results on its own stream after join() without a host synchronisation."""
+    from sir_amd.featurizer import get_featurizer
+    from sir_amd.pipeline import BatchPipeline
+    m = CNNAudioGRU(31)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    fz = get_featurizer()
+    waves = [synth.synth_clips(12, 30000 + 512 * i, seed=300 + i).to(DEV) for i in range(7)]
+    ref = []
+    for w in waves:
+        f = fz(w, t_pad=200).clone()
+        ref.append((f, *m.predict(f)))
+    torch.cuda.synchronize()
+    for n in (1, 2, 3):
+        pipe = BatchPipeline(m, n_streams=n)
+        bufs = [torch.empty(12, 64, 200, device=DEV) for _ in range(n)]
+        acc = torch.zeros(12, 31, device=DEV)
+        res = []
+        for i, w in enumerate(waves):
+            k = pipe.slot(i)
+            f = pipe.features(i, w, None, t_pad=200, out=bufs[k])
+            logits, amax = pipe.infer(i, f)
+            res.append((logits, amax))
+        pipe.join()                                   # caller's stream now waits for every slot: no host sync
+        for logits, _ in res:
+            acc += logits                              # consumed on the caller's stream
+        torch.cuda.synchronize()
+        for (f0, l0, a0), (l1, a1) in zip(ref, res):
+            assert torch.equal(l0, l1) and torch.equal(a0, a1), n
+        assert torch.equal(acc, sum(l for _, l, _ in ref)), n
+    lib = _native.lib()
+    import ctypes as C
+    bad = C.c_void_p()
+    assert lib.sir_pipeline_create(fz.handle, 5, C.byref(bad)) != 0 and b"n_slots" in lib.sir_last_error()
+
+
 @pytest.mark.parametrize("bsz,t", [(37, 120), (17, 8), (3, 333), (130, 64)])
 def test_ragged_shapes_vs_oracle(sd, bsz, t):
     """Batch sizes that do not fill the kernels' utterance groups (16 per GRU cluster, 4 per pair) and frame counts that
