@@ -2,7 +2,7 @@
 """Turn the rocprofv3 --pmc passes of devtools/gpu_pmc.sh (FETCH_SIZE and WRITE_SIZE, collected in
 separate passes) into HBM bytes per launch for the kernels bench.py reports.
 
-    python profiles/pmc_to_traffic.py gpurun_out/pmc profiles/r01
+    python profiles/pmc_to_traffic.py gpurun_out/pmc profiles/r02
 
 Corrections per MI355X_MICROARCH.md (HBM / rocprofv3): both counters are in KiB; on gfx950 FETCH_SIZE
 reports half of the bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled; WRITE_SIZE
@@ -17,7 +17,7 @@ import os
 import sys
 
 NAME_MAP = [
-    ("feat_frames_kernel", "feat_frames"), ("feat_normalise_kernel", "feat_normalise"),
+    ("feat_utt_kernel", "feat_frames"), ("feat_frames_kernel", "feat_frames"), ("feat_normalise_kernel", "feat_normalise"),
     ("conv1_mfma_bn_relu_pool_kernel", "conv1_bn_relu_pool"), ("conv1_bn_relu_pool_kernel", "conv1_bn_relu_pool"),
     ("conv3x3_bf16x6_ns_kernel<32, 64", "conv2_mfma_bn_relu_pool"), ("conv3x3_bf16x6_ns_kernel<64, 128", "conv3_mfma_bn_relu_pool"),
     ("gemm_nt_bf16x6_v3_kernel", "gemm_ih"),
@@ -39,6 +39,8 @@ def main(src, dst):
                     vals[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
                     break
     out = {}
+    if "gru_recurrence" in vals:                      # one kernel, two launches per step: bench.py reports them per layer
+        vals["gru_recurrence_l0"] = vals["gru_recurrence_l1"] = vals["gru_recurrence"]
     for name, cs in vals.items():
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             fetch = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024 * 2
@@ -52,4 +54,4 @@ def main(src, dst):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc", sys.argv[2] if len(sys.argv) > 2 else "profiles/r01")
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc", sys.argv[2] if len(sys.argv) > 2 else "profiles/r02")

@@ -9,7 +9,7 @@ import torch
 
 import cases
 from oracle import model_ref
-from sir_amd import synth
+from sir_amd import _native, synth
 from sir_amd.models.models import CNNAudioGRU
 
 pytestmark = pytest.mark.gpu
