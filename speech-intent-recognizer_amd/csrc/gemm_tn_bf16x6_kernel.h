@@ -2,26 +2,50 @@
 //
 //   dW[m][n] = sum_tok A[tok][m] * B[tok (+shift)][n]       A = dgi / dgh slice [tokens][768], B = layer input or h_prev
 // Both operands are token-major in memory, i.e. TRANSPOSED with respect to what v_mfma_f32_32x32x16_bf16 wants (eight
-// consecutive k = tokens per lane).  As in conv_wgrad_bf16x6_kernel the transposition happens while a 32-token stage is
-// written to LDS: thread = (token, 4 columns) reads a float4, splits it into the three bf16 planes and stores the 12
-// halves with ds_write_b16 into AT[plane][m][token] / BT[plane][n][token] (lanes run along the tokens); the next stage's
-// global loads are issued before the MFMAs of the current one.
+// consecutive k = tokens per lane).  The transposition is done by the LDS hardware on the way OUT: a 32-token stage is
+// written in its natural [token][column] order -- thread = (token, 4 columns) reads a float4 (lanes along the columns:
+// 512-byte coalesced rows), splits it into the three bf16 planes and issues ONE ds_write_b64 per plane -- and the MFMA
+// fragments are fetched with ds_read_b64_tr_b16 (gfx950), which hands lane i column i of a 4-token x 16-column block:
+// two of them make the lane's eight consecutive tokens.  64-byte chunks of a row are XOR-swizzled with the token index so
+// that the four rows of a transposed read fall on the four quarters of the bank line (conflict-free reads AND stores).
+// The first version transposed on the way IN with twelve 2-byte LDS stores per float4 (lanes along the tokens): timing
+// knock-outs put that staging at 67 of the dW launch's 214 us and 48 of dX's 167 us, serial with the MFMAs.
 // One launch covers up to four jobs (both directions x {W_ih, W_hh} of a layer): blockIdx.x walks the 128 x 256 output
 // tiles of all jobs, blockIdx.y the K splits; every (tile, split) writes its partial to the job's slab z (deterministic
 // slab_reduce afterwards).  8 waves, wave tile 64 x 64 (2 x 2 accumulators), 24 MFMAs per 16-token step.
-// Tried and removed: 16-token stages in two LDS buffers with the next stage's transposing stores placed between the MFMAs
-// (sched_group_barrier 2 MFMA : 10 VALU : 3 LDS stores) and one barrier per stage -- 153-158 us against 140 us for the
-// dW launch and 167-178 against 147 us for dX: the 48-byte rows make the 2-byte stores 2-way bank-conflicted and the
-// shorter MFMA runs between barriers expose more latency than the overlap hides.
+// Tried and removed: 16-token stages in two LDS buffers with the next stage's stores placed between the MFMAs
+// (sched_group_barrier 2 MFMA : 10 VALU : 3 LDS stores) and one barrier per stage -- slower than the plain two-barrier loop.
 //   seq / shift: row tok of B is taken from row tok + shift of the same length-`seq` sequence, zero outside it (the
-//   h_{t-1} / h_{t+1} operand of the W_hh gradient), as in gemm_general_kernel.
+//   h_{t-1} / h_{t+1} operand of the W_hh gradient).
 #pragma once
 #include "bf16x6_kernels.h"
 
 constexpr int TN_BM = 128, TN_BN = 256, TN_BK = 32;
-constexpr int TN_ROWB = TN_BK * 2 + 16;                      // 80 B per LDS row: 5 sixteen-byte slots (odd -> conflict-free b128 reads)
-constexpr size_t TN_LDS_BYTES = (size_t)3 * (TN_BM + TN_BN) * TN_ROWB;   // 92,160 B
-constexpr size_t TN_LDS_BYTES_64 = (size_t)3 * (64 + TN_BN) * TN_ROWB;    // 76,800 B (BM = 64)
+constexpr int TN_ROWB = TN_BK * 2 + 16;                      // k-contiguous image (A of dX): 80 B per row, 5 sixteen-byte slots (odd -> conflict-free b128 reads)
+// k-major image of an operand given as [k][x] (x contiguous): per plane 32 rows of 2 X bytes, 64-byte chunks swizzled
+constexpr size_t tn_lds_bytes(bool a_km, int bm) {
+    return (size_t)3 * (a_km ? TN_BK * bm * 2 : bm * TN_ROWB) + (size_t)3 * TN_BK * TN_BN * 2;
+}
+constexpr size_t TN_LDS_BYTES = tn_lds_bytes(false, 128);    // 79,872 B: the larger of the two BM = 128 instantiations (dW: 73,728)
+constexpr size_t TN_LDS_BYTES_64 = tn_lds_bytes(false, 64);  // 64,512 B (BM = 64)
+
+// byte offset of element (row k, byte xb of the row) in a k-major image with XW-byte rows.  The four rows k0 .. k0+3 of a
+// transposed read (k0 a multiple of 4) put their 64-byte chunk on four different quarters of the 256-byte bank line:
+//   XW >= 256: chunk c -> c ^ (k & 3);   XW = 128: chunk c -> c ^ ((k >> 1) & 1)   (rows k and k + 2 share a line half)
+template <int XW>
+__device__ __forceinline__ int tn_kmaj_off(int k, int xb) {
+    const int key = XW == 128 ? ((k >> 1) & 1) : (k & 3);
+    return k * XW + ((((xb >> 6) ^ key)) << 6) + (xb & 63);
+}
+typedef short tn_v4i16 __attribute__((ext_vector_type(4)));
+// eight consecutive k of one column as an MFMA fragment: two hardware-transposed reads (k .. k+3 and k+4 .. k+7), XW-byte rows
+template <int XW>
+__device__ __forceinline__ bf16x8 tn_tr_fragment(const unsigned char* p) {
+    struct { tn_v4i16 lo, hi; } f;
+    f.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_v4i16 __attribute__((address_space(3)))*)(p));
+    f.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_v4i16 __attribute__((address_space(3)))*)(p + 4 * XW));
+    return __builtin_bit_cast(bf16x8, f);
+}
 
 struct TnJobs {
     const float* A[4]; const float* B[4]; float* slab[4];   // slab[j] + z * slab_stride[j] receives split z of job j
@@ -41,9 +65,11 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
     static_assert(BM == 128 || BM == 64, "tile rows");
     constexpr int NC = BM == 128 ? 2 : 1;                    // 32-column accumulators per wave
     constexpr int NAQ = BM * 8 / 512;                        // A staging items per thread
+    constexpr int AXW = BM * 2, BXW = TN_BN * 2;             // row bytes of the k-major images
+    constexpr int APLANE = A_KM ? TN_BK * AXW : BM * TN_ROWB, BPLANE = TN_BK * BXW;
     extern __shared__ __attribute__((aligned(16))) unsigned char tl[];
-    unsigned char* AT = tl;                                  // [3][BM][80]
-    unsigned char* BT = tl + (size_t)3 * BM * TN_ROWB;       // [3][256][80]
+    unsigned char* AT = tl;                                  // A_KM: [3][32 tok][BM] k-major, swizzled; else [3][BM][80] k-contiguous
+    unsigned char* BT = tl + (size_t)3 * APLANE;             // [3][32 k][256] k-major, swizzled
     int j = 0;
     while (j + 1 < jobs.njobs && (int)blockIdx.x >= jobs.tile0[j + 1]) ++j;
     const int tile = blockIdx.x - jobs.tile0[j];
@@ -58,23 +84,25 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = BM == 128 ? wv >> 2 : 0, wn = BM == 128 ? wv & 3 : wv, i32 = lane & 31, kgrp = lane >> 5;
 
-    // staging items: token = it % 32, 4-column group = it / 32.  A: 128 / 4 * 32 = 1024 items (2 per thread), B: 2048 (4)
+    // staging items, lanes along the columns (coalesced 16-byte loads, 128 contiguous LDS bytes per 16-lane store group):
+    //   A_KM : A item = (4-column group it % (BM/4), token it / (BM/4)); else A item = (row it / 8, four consecutive k)
+    //   B    : item = (4-column group it % 64, token it / 64)
     float4 pa[NAQ], pb[4];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < NAQ; ++q) {
             const int it = tid + 512 * q;
             if (A_KM) {
-                const int tok = k0 + (it & 31), m = m0 + 4 * (it >> 5);
+                const int tok = k0 + it / (BM / 4), m = m0 + 4 * (it % (BM / 4));
                 pa[q] = (tok < k_end && m < M) ? *reinterpret_cast<const float4*>(A + (size_t)tok * lda + m) : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {                                         // item = (row it / 8, four consecutive k)
+            } else {
                 const int m = m0 + (it >> 3), k = k0 + 4 * (it & 7);
                 pa[q] = (k < k_end && m < M) ? *reinterpret_cast<const float4*>(A + (size_t)m * lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int it = tid + 512 * q, tok = k0 + (it & 31), n = n0 + 4 * (it >> 5);
+            const int it = tid + 512 * q, tok = k0 + (it >> 6), n = n0 + 4 * (it & 63);
             bool ok = tok < k_end && n < N;
             int src = tok;
             if (shift != 0) {                                // neighbouring time step of the same utterance
@@ -86,38 +114,27 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
             pb[q] = ok ? *reinterpret_cast<const float4*>(bsrc + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto put = [&](const float4& v, unsigned char* base, size_t plane, int row4, int tok) {
-        uint2 hh, mm, ll;
-        split3_quad(v, hh, mm, ll);
-        unsigned char* d = base + (size_t)row4 * TN_ROWB + tok * 2;
-        const unsigned hw[4] = {hh.x & 0xFFFFu, hh.x >> 16, hh.y & 0xFFFFu, hh.y >> 16};
-        const unsigned mw[4] = {mm.x & 0xFFFFu, mm.x >> 16, mm.y & 0xFFFFu, mm.y >> 16};
-        const unsigned lw[4] = {ll.x & 0xFFFFu, ll.x >> 16, ll.y & 0xFFFFu, ll.y >> 16};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            *reinterpret_cast<unsigned short*>(d + (size_t)e * TN_ROWB) = (unsigned short)hw[e];
-            *reinterpret_cast<unsigned short*>(d + plane + (size_t)e * TN_ROWB) = (unsigned short)mw[e];
-            *reinterpret_cast<unsigned short*>(d + 2 * plane + (size_t)e * TN_ROWB) = (unsigned short)lw[e];
-        }
-    };
     auto stage = [&]() {
 #pragma unroll
         for (int q = 0; q < NAQ; ++q) {
             const int it = tid + 512 * q;
-            if (A_KM) put(pa[q], AT, (size_t)BM * TN_ROWB, 4 * (it >> 5), it & 31);
-            else {
-                uint2 hh, mm, ll;
-                split3_quad(pa[q], hh, mm, ll);
-                unsigned char* d = AT + (size_t)(it >> 3) * TN_ROWB + (it & 7) * 8;
-                *reinterpret_cast<uint2*>(d) = hh;
-                *reinterpret_cast<uint2*>(d + (size_t)BM * TN_ROWB) = mm;
-                *reinterpret_cast<uint2*>(d + 2 * (size_t)BM * TN_ROWB) = ll;
-            }
+            uint2 hh, mm, ll;
+            split3_quad(pa[q], hh, mm, ll);
+            unsigned char* d = A_KM ? AT + tn_kmaj_off<AXW>(it / (BM / 4), 8 * (it % (BM / 4)))
+                                    : AT + (size_t)(it >> 3) * TN_ROWB + (it & 7) * 8;
+            *reinterpret_cast<uint2*>(d) = hh;
+            *reinterpret_cast<uint2*>(d + APLANE) = mm;
+            *reinterpret_cast<uint2*>(d + 2 * APLANE) = ll;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int it = tid + 512 * q;
-            put(pb[q], BT, (size_t)TN_BN * TN_ROWB, 4 * (it >> 5), it & 31);
+            uint2 hh, mm, ll;
+            split3_quad(pb[q], hh, mm, ll);
+            unsigned char* d = BT + tn_kmaj_off<BXW>(it >> 6, 8 * (it & 63));
+            *reinterpret_cast<uint2*>(d) = hh;
+            *reinterpret_cast<uint2*>(d + BPLANE) = mm;
+            *reinterpret_cast<uint2*>(d + 2 * BPLANE) = ll;
         }
     };
 
@@ -129,14 +146,27 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
 
-    const unsigned char* arow = AT + (size_t)(wm * 64 + i32) * TN_ROWB + kgrp * 16;
-    const unsigned char* brow = BT + (size_t)(wn * 32 * NC + i32) * TN_ROWB + kgrp * 16;
+    // fragment addresses.  Transposed read (cdna_hip_programming.md T10): the 16 lanes 16 g .. 16 g + 15 fetch a block of
+    // 4 k-rows x 16 columns; lane 4 q + p supplies the address of row q, columns 4 p .. 4 p + 3 and receives column
+    // (lane & 15).  For the 32 x 32 x 16 operand, group g covers columns 16 (g & 1) .. + 15 of the wave's 32-column tile
+    // and k = 8 (g >> 1) .. + 7 of the 16-deep step (two reads: k .. k + 3, k + 4 .. k + 7).
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tcol = 16 * ((lane >> 4) & 1) + 4 * tp, tk = 8 * (lane >> 5) + tq;
+    const unsigned char* arow[2];
+    const unsigned char* brow[NC];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+        arow[a] = A_KM ? AT + tn_kmaj_off<AXW>(tk, 2 * (wm * 64 + a * 32 + tcol))
+                       : AT + (size_t)(wm * 64 + a * 32 + i32) * TN_ROWB + kgrp * 16;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) brow[c] = BT + tn_kmaj_off<BXW>(tk, 2 * (wn * 32 * NC + c * 32 + tcol));
     fetch(k_begin);
     for (int k0 = k_begin; k0 < k_end; k0 += TN_BK) {
         __syncthreads();                                     // previous stage consumed
         stage();
-        if (k0 + TN_BK < k_end) fetch(k0 + TN_BK);           // in flight during this stage's MFMAs
         __syncthreads();
+        // issued AFTER the barrier (a __syncthreads() in front of the loads' consumers would wait for them: it drains vmcnt):
+        // in flight during this stage's MFMAs, waited for at the next stage's first barrier
+        if (k0 + TN_BK < k_end) fetch(k0 + TN_BK);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 af[2][3], bf[NC][3];
@@ -144,10 +174,10 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
             for (int p = 0; p < 3; ++p) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
-                    af[a][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(arow + (size_t)p * BM * TN_ROWB + (size_t)a * 32 * TN_ROWB + s * 32));
+                    af[a][p] = A_KM ? tn_tr_fragment<AXW>(arow[a] + p * APLANE + s * 16 * AXW)
+                                    : __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(arow[a] + (size_t)p * APLANE + s * 32));
 #pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    bf[c][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(brow + (size_t)p * TN_BN * TN_ROWB + (size_t)c * 32 * TN_ROWB + s * 32));
+                for (int c = 0; c < NC; ++c) bf[c][p] = tn_tr_fragment<BXW>(brow[c] + p * BPLANE + s * 16 * BXW);
             }
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
 #pragma unroll

@@ -50,27 +50,31 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16x6_kernel(const float* __r
     //   fetch_row : float4 loads of the thread's items (pixel fastest, then 4-channel group) into registers,
     //   write_row : split into the three bf16 planes and transposed 2-byte stores planes[P][c][pixel + poff].
     constexpr int MAXW = wgrad_x6_max_w(COUT);                 // the host checks W <= MAXW (the LDS image bounds it anyway)
-    constexpr int NZ = (MAXW * (COUT / 4) + 511) / 512, NA = (MAXW * (CIN / 4) + 511) / 512;   // float4 items per thread
+    // staging items: thread = (pixel px = tid % MAXW, channel group c4 = tid / MAXW + (512 / MAXW) * k) -- a power-of-two
+    // split, so an item's address is two small integers away from the row base.  (Items numbered it = tid + 512 k with
+    // it % W / it / W kept one 64-bit offset per item alive; those spilled, and every reload -- a scratch load, counted in
+    // vmcnt -- put an s_waitcnt vmcnt(0) in front of the next global load: the row's six loads were issued one at a time.)
+    constexpr int GPP = 512 / MAXW;                            // channel groups covered per pass of the 512 threads
+    constexpr int NZ = (COUT / 4) / GPP, NA = (CIN / 4) / GPP; // float4 items per thread
+    static_assert((COUT / 4) % GPP == 0 && (CIN / 4) % GPP == 0, "staging passes");
+    const int spx = tid & (MAXW - 1), sg = tid / MAXW;
+    const bool spx_ok = spx < W;
     auto fetch_row = [&](const float* src, int C, auto& regs) {
-        const int items = W * (C / 4);
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(regs) / sizeof(float4)); ++k) {
-            const int it = tid + 512 * k;
             regs[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (src && it < items) regs[k] = *reinterpret_cast<const float4*>(src + (size_t)(it % W) * C + 4 * (it / W));
+            if (src && spx_ok) regs[k] = *reinterpret_cast<const float4*>(src + spx * C + 4 * (sg + GPP * k));
         }
     };
     auto write_row = [&](const auto& regs, int C, unsigned char* base, int rowb, int poff) {
-        const int items = W * (C / 4);
         const size_t plane = (size_t)C * rowb;
+        if (!spx_ok) return;
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(regs) / sizeof(float4)); ++k) {
-            const int it = tid + 512 * k;
-            if (it >= items) continue;
-            const int px = it % W, c4 = it / W;
+            const int c4 = sg + GPP * k;
             uint2 hh, mm, ll;
             split3_quad(regs[k], hh, mm, ll);
-            unsigned char* d = base + (size_t)(4 * c4) * rowb + (px + poff) * 2;
+            unsigned char* d = base + (size_t)(4 * c4) * rowb + (spx + poff) * 2;
             const unsigned hw[4] = {hh.x & 0xFFFFu, hh.x >> 16, hh.y & 0xFFFFu, hh.y >> 16};
             const unsigned mw[4] = {mm.x & 0xFFFFu, mm.x >> 16, mm.y & 0xFFFFu, mm.y >> 16};
             const unsigned lw[4] = {ll.x & 0xFFFFu, ll.x >> 16, ll.y & 0xFFFFu, ll.y >> 16};
@@ -103,11 +107,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16x6_kernel(const float* __r
         __syncthreads();                                       // previous row fully consumed
         write_row(pa, CIN, a_slot(y + 1), rowa, 1);
         write_row(pz, COUT, dzT, rowz, 0);
-        if (y + 1 < y0 + RB) {                                 // next row's loads fly during this row's MFMAs
+        __syncthreads();
+        // The next row's loads are issued AFTER the barrier: __syncthreads() drains vmcnt, so loads issued in front of it
+        // were waited for right there (knock-out timing: 86 of the kernel's 275 us were exposed fetch time); issued here
+        // they fly during this row's MFMAs and are only waited for at the next row's first barrier.
+        if (y + 1 < y0 + RB) {
             fetch_row(a_src(y + 2), CIN, pa);
             fetch_row(dz + (((size_t)b * H + y + 1) * W) * COUT, COUT, pz);
         }
-        __syncthreads();
         const unsigned char* zrow = dzT + (size_t)(mt * 32 + i32) * rowz + kgrp * 16;
         for (int s = ks; s < nks; s += KSPLIT) {
             bf16x8 afr[3];
