@@ -52,6 +52,8 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     h->status = nullptr;
     h->cluster_done = nullptr; h->cluster_stream = nullptr; h->cluster_pending = false;
     h->attr_gemm_v3 = h->attr_gru_quad = h->attr_gru_bwd = h->attr_tn = h->attr_wgrad = false;
+    for (auto& x : h->xbufs) { x.p = nullptr; x.kind = 0; x.bytes = 0; x.epoch = 0; }
+    h->xbuf_next = 0;
     h->cfg = *cfg;
     h->cfg.window = nullptr;
     h->cfg.mel_fb = nullptr;

@@ -26,7 +26,7 @@ constexpr size_t GBP_LDS_BYTES = ((size_t)GBP_LDS4 * GP_THREADS * 4 + GP_BW * 38
 __global__ __launch_bounds__(GP_THREADS) void gru_bwd_pair_kernel(
     const float* __restrict__ dy, const float* __restrict__ gates, const float* __restrict__ y, const float* __restrict__ whh0,
     const float* __restrict__ whh1, float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ bsum_i,
-    float* __restrict__ bsum_h, int B, int S, float* xbuf, unsigned int* status) {
+    float* __restrict__ bsum_h, int B, int S, float* xbuf, unsigned int* status, unsigned epoch) {
     extern __shared__ __attribute__((aligned(16))) float blds[];
     gp_f4* wl4 = reinterpret_cast<gp_f4*>(blds);                          // [GBP_LDS4][threads] float4 (4 consecutive own rows)
     float* gsh = blds + (size_t)GBP_LDS4 * GP_THREADS * 4;                // dgh of the own rows: [utterance][384]
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(GP_THREADS) void gru_bwd_pair_kernel(
 #pragma unroll
         for (int bb = 1; bb < GP_BW; ++bb) { s0 = (rp == bb) ? acc0[bb] : s0; s1 = (rp == bb) ? acc1[bb] : s1; }
         const float vown = half ? s1 : s0, vpeer = half ? s0 : s1;
-        const unsigned tagv = (unsigned)(it + 1);
+        const unsigned tagv = (epoch << 16) | (unsigned)(it + 1);     // {launch epoch of this buffer, step + 1}: stale granules never match
         if (it + 1 < S) {
             unsigned long long* gslot = xg + ((size_t)(it & 1) * 2 + half) * GP_BW * GP_UH;
             const unsigned long long* gpeer = xg + ((size_t)(it & 1) * 2 + (half ^ 1)) * GP_BW * GP_UH;

@@ -12,9 +12,10 @@ int sir_launch_gru_bwd_pair(sir_handle* h, hipStream_t st, const float* dy, cons
         h->attr_gru_bwd = true;
     }
     const size_t npairs = (B + GP_BW - 1) / GP_BW;
-    SIR_HIP_TRY(hipMemsetAsync(xbuf, 0, npairs * 2 * 2 * 2 * GP_BW * GP_UH * 8, st));     // tags are re-armed before every launch
+    unsigned epoch = 0;
+    if (sir_xbuf_epoch(h, st, xbuf, 2, npairs * 2 * 2 * 2 * GP_BW * GP_UH * 8, 0xFFFFu, &epoch) != SIR_OK) return SIR_EHIP;
     hipLaunchKernelGGL(gru_bwd_pair_kernel, dim3((unsigned)(npairs * 2), 2), dim3(GP_THREADS), GBP_LDS_BYTES, st, dy, gates, y, whh0, whh1, dgi,
-                       dgh, bsum_i, bsum_h, B, S, xbuf, h->status);
+                       dgh, bsum_i, bsum_h, B, S, xbuf, h->status, epoch);
     SIR_HIP_TRY(hipGetLastError());
     return SIR_OK;
 }

@@ -3,11 +3,10 @@
 #include "gru_quad_kernel.h"
 
 static size_t gru_quad_xbuf_bytes(int batch) { return (size_t)((batch + GQ_NU - 1) / GQ_NU) * 2 * GQ_XBUF_PER_CLUSTER; }
-size_t sir_gru_bwd_xbuf_bytes(int batch);      // gru_pair.hip
-size_t sir_gru_xbuf_bytes(int batch) {
-    const size_t q = gru_quad_xbuf_bytes(batch), p = sir_gru_bwd_xbuf_bytes(batch);
-    return q > p ? q : p;
-}
+// forward granules first, the BPTT kernel's region behind them: the two formats never share bytes, so neither kernel can
+// ever mistake the other's stale granule for its own tag
+size_t sir_gru_xbuf_bytes(int batch) { return sir_gru_bwd_xbuf_offset(batch) + sir_gru_bwd_xbuf_bytes(batch); }
+size_t sir_gru_bwd_xbuf_offset(int batch) { return sir_align_up(gru_quad_xbuf_bytes(batch), 256); }
 
 int sir_launch_gru_quad(sir_handle* h, hipStream_t st, bool save, const float* gi, const float* whh0, const float* whh1, const float* bhh0,
                         const float* bhh1, float* y, int B, int S, float* gates, float* xbuf, unsigned short* yplanes, const void* wfrag0,
@@ -17,18 +16,19 @@ int sir_launch_gru_quad(sir_handle* h, hipStream_t st, bool save, const float* g
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_quad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GQ_LDS_BYTES));
         h->attr_gru_quad = true;
     }
-    if (S >= 65535) { sir_set_error("gru_quad: %d steps exceed the 16-bit step tag", S); return SIR_EUNSUPPORTED; }
+    if (S >= 511) { sir_set_error("gru_quad: %d steps exceed the 9-bit step field of the granule tag", S); return SIR_EUNSUPPORTED; }
     const int clusters = ((B + GQ_NU - 1) / GQ_NU) * 2;
-    SIR_HIP_TRY(hipMemsetAsync(xbuf, 0, (size_t)clusters * GQ_XBUF_PER_CLUSTER, st));     // tags are re-armed before every launch
+    unsigned epoch = 0;
+    if (sir_xbuf_epoch(h, st, xbuf, 1, (size_t)clusters * GQ_XBUF_PER_CLUSTER, 127u, &epoch) != SIR_OK) return SIR_EHIP;
     const dim3 grid(4, (unsigned)clusters);
     // SIR_GRU_DBG: timing knock-outs and fault injection of gru_quad_kernel (see its `dbg` comment); 0 in production
     static const int dbg = getenv("SIR_GRU_DBG") ? atoi(getenv("SIR_GRU_DBG")) : 0;
     if (save)
         hipLaunchKernelGGL(gru_quad_kernel<true>, grid, dim3(GQ_THREADS), GQ_LDS_BYTES, st, gi, whh0, whh1, bhh0, bhh1, y, B, S, gates,
-                           (unsigned long long*)xbuf, h->status, dbg, yplanes, (const uint4*)wfrag0, (const uint4*)wfrag1);
+                           (unsigned long long*)xbuf, h->status, dbg, epoch, yplanes, (const uint4*)wfrag0, (const uint4*)wfrag1);
     else
         hipLaunchKernelGGL(gru_quad_kernel<false>, grid, dim3(GQ_THREADS), GQ_LDS_BYTES, st, gi, whh0, whh1, bhh0, bhh1, y, B, S, gates,
-                           (unsigned long long*)xbuf, h->status, dbg, yplanes, (const uint4*)wfrag0, (const uint4*)wfrag1);
+                           (unsigned long long*)xbuf, h->status, dbg, epoch, yplanes, (const uint4*)wfrag0, (const uint4*)wfrag1);
     SIR_HIP_TRY(hipGetLastError());
     return SIR_OK;
 }

@@ -60,13 +60,15 @@ static __global__ __launch_bounds__(256) void prep_whh_quad_kernel(const float* 
     o[128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
 }
 
-// xbuf   [clusters][2 parity][4 quarters][16 utterances][64 units] 8-byte granules, zeroed before every launch
+// xbuf   [clusters][2 parity][4 quarters][16 utterances][64 units] 8-byte granules; the 16-bit tag is {7-bit launch epoch of
+//        this buffer, 9-bit step + 1}: a granule of an earlier launch never matches, so the buffer is zeroed only when it is
+//        new or grows (sir_xbuf_epoch), not before every launch
 // status set to 1 if a spin times out (results are then invalid; cannot happen while a cluster is co-resident)
 template <bool SAVE>
 __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     const float* __restrict__ gi, const float* __restrict__ whh0, const float* __restrict__ whh1,
     const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ y, int B, int S,
-    float* __restrict__ gates, unsigned long long* xbuf, unsigned int* status, int dbg, unsigned short* __restrict__ yplanes,
+    float* __restrict__ gates, unsigned long long* xbuf, unsigned int* status, int dbg, unsigned epoch, unsigned short* __restrict__ yplanes,
     const uint4* __restrict__ wfrag0, const uint4* __restrict__ wfrag1) {
     // wfrag0/1 (optional): prep_whh_quad_kernel output for direction 0 / 1
     // yplanes (optional): bf16x3 planes [3][B * S][512] of y, the A operand of the next layer's input projection
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
         }
         if (!(dbg & 4) && !((dbg & 8) && q == 3)) {
             unsigned long long* gs = xc + (((size_t)(step & 1) * 4 + q) * GQ_NU + n) * GQ_UQ + (u0 - q * GQ_UQ);
-            const unsigned long long tag = (unsigned long long)(unsigned)(step + 1) << 48;
+            const unsigned long long tag = (unsigned long long)((epoch << 9) | (unsigned)(step + 1)) << 48;
             const unsigned hh_[4] = {ph.x & 0xFFFFu, ph.x >> 16, ph.y & 0xFFFFu, ph.y >> 16};
             const unsigned mm_[4] = {pm.x & 0xFFFFu, pm.x >> 16, pm.y & 0xFFFFu, pm.y >> 16};
             const unsigned ll_[4] = {pl.x & 0xFFFFu, pl.x >> 16, pl.y & 0xFFFFu, pl.y >> 16};
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
             // repeated as a whole until every tag matches -- a per-granule retry serialises the round trips
             unsigned long long v[3][4];
             unsigned spins = 0;
-            const unsigned long long want = (unsigned long long)(unsigned)(step + 1);
+            const unsigned long long want = (unsigned long long)((epoch << 9) | (unsigned)(step + 1));
             const unsigned long long* src0 = xc + ((size_t)(step & 1) * 4 * GQ_NU + rn) * GQ_UQ + ru4 * 4;
             for (;;) {
 #pragma unroll

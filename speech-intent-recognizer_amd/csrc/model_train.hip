@@ -99,7 +99,7 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     n[TB_DA1] = n[TB_A1];
     n[TB_SMALL] = B * 512 + B + 64 + (size_t)d.c1gx * d.c1gy * B * 352;      // conv1 backward partials: 32 x 11 per block
     size_t slab = (size_t)d.wg3_blocks * 9 * 128 * 64;
-    const size_t s_w2 = (size_t)d.wg2_blocks * wgrad_x6_ksplit(32, 64) * 9 * 64 * 32, s_g = (size_t)d.ksplits * 768 * 1024;
+    const size_t s_w2 = (size_t)d.wg2_blocks * 9 * 64 * 32, s_g = (size_t)d.ksplits * 768 * 1024;
     if (s_w2 > slab) slab = s_w2;
     if (s_g > slab) slab = s_g;
     for (int in_sz : {1024, 512}) {                       // slabs of the four-job bf16x6 weight-gradient launch (size independent of the batch)
@@ -376,7 +376,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         { SirProfScope prof(h, layer ? SIR_K_B_GRU1 : SIR_K_B_GRU0, st);
         if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
         rc = sir_launch_gru_bwd_pair(h, st, dy, gates, yout, w->gru_w_hh[2 * layer], w->gru_w_hh[2 * layer + 1], p.dgi, p.dgh, bsum_i, bsum_h,
-                                     B, S, p.gxb);
+                                     B, S, p.gxb + sir_gru_bwd_xbuf_offset(B) / 4);
         if (rc != SIR_OK) return rc;
         if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP;
         // bias gradients first: bsum_* alias the slab area used below
@@ -481,7 +481,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             SirProfScope prof(h, SIR_K_B_WGRAD3, st);
             const size_t ldsx = wgrad_x6_lds_bytes(64, 128, d.wp2);
             if (ldsx > 160 * 1024 || d.wp2 > wgrad_x6_max_w(128)) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
-            const int nslab3 = d.wg3_blocks * wgrad_x6_ksplit(64, 128);
+            const int nslab3 = d.wg3_blocks;                  // one slab per workgroup
             hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<64, 128>), dim3(d.wg3_blocks), dim3(512), ldsx, st, (const float*)p.dz3,
                                (const float*)p.a2, p.slab, 16, d.wp2, d.wg3_rb);
             float* part = p.slab + (size_t)nslab3 * 9 * 128 * 64;
@@ -519,7 +519,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             SirProfScope prof(h, SIR_K_B_WGRAD2, st);
             const size_t ldsx = wgrad_x6_lds_bytes(32, 64, d.wp1);
             if (ldsx > 160 * 1024 || d.wp1 > wgrad_x6_max_w(64)) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
-            const int nslab2 = d.wg2_blocks * wgrad_x6_ksplit(32, 64);
+            const int nslab2 = d.wg2_blocks;                  // one slab per workgroup (its four k-split waves add up in LDS)
             hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<32, 64>), dim3(d.wg2_blocks), dim3(512), ldsx, st, (const float*)p.dz2,
                                (const float*)p.a1, p.slab, 32, d.wp1, d.wg2_rb);
             float* part = p.slab + (size_t)nslab2 * 9 * 64 * 32;

@@ -71,7 +71,35 @@ struct sir_handle {
     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) latches, per handle = per device (a process-wide static would skip
     // the second device of a process that drives several)
     bool attr_gemm_v3, attr_gru_quad, attr_gru_bwd, attr_tn, attr_wgrad;
+    // exchange-granule buffers of the cluster kernels seen by this handle: {buffer, kind, bytes the previous launch on it
+    // covered, launch epoch}.  The epoch goes into every granule's tag, so a buffer is
+    // zeroed when it is new to the handle or needs more bytes than before -- not before every launch (4.8 us each, 4 per
+    // training step / 2 per inference batch, serialised in front of a latency-bound kernel).
+    struct XbufEntry { const void* p; int kind; size_t bytes; unsigned epoch; };
+    XbufEntry xbufs[8];
+    int xbuf_next;
 };
+
+// launch epoch for a cluster kernel's granule buffer; zeroes it first when needed.  `kind` separates kernels that share
+// one buffer with different granule formats (their tags cannot match each other's: gru_quad_kernel.h / gru_bwd_pair_kernel.h)
+static inline int sir_xbuf_epoch(sir_handle* h, hipStream_t st, void* xbuf, int kind, size_t bytes, unsigned mask, unsigned* epoch) {
+    sir_handle::XbufEntry* e = nullptr;
+    for (auto& x : h->xbufs)
+        if (x.p == xbuf && x.kind == kind) e = &x;
+    if (!e) {
+        e = &h->xbufs[h->xbuf_next];
+        h->xbuf_next = (h->xbuf_next + 1) % 8;
+        e->p = xbuf; e->kind = kind; e->bytes = 0; e->epoch = 0;
+    }
+    // new buffer, or more clusters than the PREVIOUS launch on it wrote: the extra granules are older than one epoch (after a
+    // run of 128 smaller batches they would carry the current epoch again) -- zero.  Otherwise every granule that will be
+    // polled was written by the previous launch, whose epoch differs.
+    if (bytes > e->bytes && hipMemsetAsync(xbuf, 0, bytes, st) != hipSuccess) return SIR_EHIP;
+    e->bytes = bytes;
+    e->epoch = (e->epoch + 1) & mask;
+    *epoch = e->epoch;
+    return SIR_OK;
+}
 
 // bracket of a cluster-kernel launch (see sir_handle::cluster_done)
 static inline int sir_cluster_enter(sir_handle* h, hipStream_t st) {
@@ -129,7 +157,9 @@ int sir_features_launch(sir_handle* h, const void* wave, int wave_dtype, int64_t
 
 // GRU recurrences (gru_quad.hip: forward, clusters of four workgroups on the matrix cores; gru_pair.hip: BPTT, pairs of
 // workgroups).  Both write h->status if an exchange spin times out.
-size_t sir_gru_xbuf_bytes(int batch);          // exchange-granule workspace: the larger of the two kernels' needs
+size_t sir_gru_xbuf_bytes(int batch);          // exchange-granule workspace: forward region + BPTT region
+size_t sir_gru_bwd_xbuf_offset(int batch);     // byte offset of the BPTT kernel's region
+size_t sir_gru_bwd_xbuf_bytes(int batch);
 int sir_launch_gru_quad(sir_handle* h, hipStream_t st, bool save, const float* gi, const float* whh0, const float* whh1, const float* bhh0,
                         const float* bhh1, float* y, int B, int S, float* gates, float* xbuf,
                         unsigned short* yplanes = nullptr, const void* wfrag0 = nullptr, const void* wfrag1 = nullptr);
