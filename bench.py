@@ -302,6 +302,7 @@ def main():
     ap.add_argument("--augment", dest="augment", action="store_true", default=True,
                     help="also time the training step with fused time-shift + noise + SpecAugment masks (default on)")
     ap.add_argument("--no-augment", dest="augment", action="store_false")
+    ap.add_argument("--no-host-feed", action="store_true", help="skip the training leg fed from pinned host memory")
     ap.add_argument("--train-steps", type=int, default=20)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("SIR_BENCH_STREAMS", "2")),
                     help="HIP streams the inference batches alternate over (each with its own buffers/workspace)")
@@ -534,6 +535,43 @@ def main():
         train_info = train_leg(False)
         if args.augment:
             train_aug_info = train_leg(True)
+        if world == 1 and not args.no_host_feed:
+            # the same training step fed from HOST memory -- pinned PCM16 batches (24.6 MB each, what a
+            # loader would hand over), copied and featurised one batch ahead on a side stream (FeaturePrefetcher) -- so that
+            # the PCIe-inclusive rate is a measured number, not an estimate.  Never the headline `value`.
+            from sir_amd.pipeline import FeaturePrefetcher
+            host_pool = [(p.clamp(-1, 1) * 32767).round().to(torch.int16).cpu().pin_memory() for p in pool[:4]]
+            pre = FeaturePrefetcher(t_pad=T_PAD)
+
+            def submit(i):
+                with torch.cuda.stream(pre.stream):               # the copy itself runs on the side stream, beside the step
+                    w = host_pool[i % len(host_pool)].to(dev, non_blocking=True)
+                pre.submit(w, lengths)
+
+            submit(0)
+
+            def hstep(i):
+                x = pre.get()
+                submit(i + 1)                                  # H2D copy + feature kernel of the next batch, side stream
+                opt.zero_grad(set_to_none=True)
+                loss = train_ops.fused_cross_entropy(model(x), labels)
+                loss.backward()
+                opt.step()
+                pre.release()
+
+            for i in range(3):
+                hstep(i)
+            torch.cuda.synchronize()
+            ht = timed_regions(hstep, args.train_steps, args.repeats)
+            h_el = statistics.median(ht)
+            train_info["host_fed"] = {"value": round(batch * args.train_steps / h_el, 1), "unit": "utterances/s",
+                                      "ms_per_step": round(h_el / args.train_steps * 1e3, 4),
+                                      "timed_regions": region_stats(ht, args.train_steps),
+                                      "feed": "pinned host PCM16 [256, 48000] per step (24.6 MB over PCIe) -> H2D on a side stream -> "
+                                              "feature kernel one batch ahead (FeaturePrefetcher) -> the same training step",
+                                      "h2d_GBs_needed": round(batch * CLIP_LEN * 2 * args.train_steps / h_el / 1e9, 2)}
+            if rank == 0:
+                log(f"train leg fed from host memory: {train_info['host_fed']['value']} utt/s")
         model.eval()
     ops.check_status()                                          # a timed-out GRU recurrence would invalidate every figure
 
