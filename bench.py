@@ -599,7 +599,7 @@ def main():
                         "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None,
                         "avg_launch_ms": round(d_ms, 5), "launches": dom_cnt[dominant],
                         "bytes_per_launch": FEATURE_BYTES_PER_UTT * batch}
-        feat_ms = kernel_ms.get("feat_frames", 0.0) + kernel_ms.get("feat_normalise", 0.0)
+        feat_ms = kernel_ms.get("feat_frames", 0.0)      # ONE fused kernel since round 2 (profile id "feat_frames")
         gru = {}
         for k, algo in GRU_ALGO_BYTES.items():
             algo = algo * batch // BATCH
@@ -623,7 +623,7 @@ def main():
                                      "v_mfma_f32_32x32x16_bf16 products, f32 accumulation), everything else fp32 VALU"},
             "dist": dist_info,
             "roofline": roofline,
-            "kernels_avg_ms": {k: round(kernel_ms[k], 5) for k in infer_names},
+            "kernels_avg_ms": {k: round(kernel_ms[k], 5) for k in infer_names if kernel_ms[k] > 0.0},
             "features_stage": {"bound": "hbm", "avg_ms": round(feat_ms, 5),
                                "achieved_GBs": round(FEATURE_BYTES_PER_UTT * batch / (feat_ms * 1e-3) / 1e9, 1) if feat_ms else None,
                                "peak_GBs": PEAK_HBM_GBS, "frac": round(FEATURE_BYTES_PER_UTT * batch / (feat_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if feat_ms else None,

@@ -47,6 +47,14 @@ __device__ __forceinline__ bf16x8 tn_tr_fragment(const unsigned char* p) {
     return __builtin_bit_cast(bf16x8, f);
 }
 
+// keep mask of the inter-layer dropout (same function as train_kernels.h dropout_keep; the dX GEMM of layer 1 applies the
+// dropout BACKWARD in its epilogue: its output IS d(dropout(y0)), and y0's gradient is that times the mask / (1 - p))
+__device__ __forceinline__ bool tn_dropout_keep(unsigned long long seed, size_t idx, float p) {
+    unsigned long long x = seed ^ (idx * 0x9E3779B97F4A7C15ull);
+    x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull; x ^= x >> 33;
+    return (float)(unsigned)(x >> 40) * (1.0f / 16777216.0f) >= p;
+}
+
 struct TnJobs {
     const float* A[4]; const float* B[4]; float* slab[4];   // slab[j] + z * slab_stride[j] receives split z of job j
     const float* B2[4]; int brows[4];                        // rows k >= brows[j] of B come from B2[j] (two stacked matrices); 0 = off
@@ -54,6 +62,8 @@ struct TnJobs {
     size_t slab_stride[4];
     int tile0[5];                                            // first tile index of each job (prefix sums), tile0[njobs] = total
     int njobs;
+    float drop_p;                                            // > 0: out[m][n] *= keep(drop_seed, m * N + n) / (1 - drop_p)
+    unsigned long long drop_seed;
 };
 
 // A_KM = true : A is [K][lda] (m contiguous: dW = dG^T X), staged transposed like B.
@@ -199,7 +209,11 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
-                if (m < M) out[(size_t)m * N + n] = acc[a][c][r];
+                if (m < M) {
+                    float v = acc[a][c][r];
+                    if (jobs.drop_p > 0.0f) v = tn_dropout_keep(jobs.drop_seed, (size_t)m * N + n, jobs.drop_p) ? v * (1.0f / (1.0f - jobs.drop_p)) : 0.0f;
+                    out[(size_t)m * N + n] = v;
+                }
             }
         }
 }

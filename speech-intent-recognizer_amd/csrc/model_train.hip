@@ -291,14 +291,14 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP; }
     if (rc != SIR_OK) return rc;
     const float* y0in = p.y0;
-    if (dropout_p > 0.0f) {
-        SirProfScope prof(h, SIR_K_T_DROPOUT, st);
-        hipLaunchKernelGGL(dropout_kernel, dim3(grid_for((size_t)M * 512)), dim3(256), 0, st, p.y0, p.y0d, (size_t)M * 512,
+    { SirProfScope prof(h, SIR_K_T_GEMM_IH1, st);
+    if (dropout_p > 0.0f) {                                   // dropout + the bf16x3 planes of its output in one pass
+        hipLaunchKernelGGL(dropout_split3_kernel, dim3(2048), dim3(256), 0, st, (const float*)p.y0, p.y0d, p.xs, (size_t)M * 512,
                            dropout_p, (unsigned long long)dropout_seed);
         y0in = p.y0d;
+    } else {
+        hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, y0in, 512, p.xs, (size_t)M, 512);
     }
-    { SirProfScope prof(h, SIR_K_T_GEMM_IH1, st);
-    hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, y0in, 512, p.xs, (size_t)M, 512);
     SIR_HIP_TRY(launch_gemm_nt_bf16x6(h, st, (const unsigned short*)p.xs, (const unsigned short*)p.wsl1,
                        (const unsigned short*)(p.wsl1 + (size_t)3 * 768 * 512), w->gru_b_ih[2], w->gru_b_ih[3], p.gi, 1536, M, 768, 512)); }
     { SirProfScope prof(h, SIR_K_T_GRU1, st);
@@ -362,8 +362,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
     hipLaunchKernelGGL(fc_wgrad_kernel, dim3(C, 2), dim3(256), 0, st, dlogits, (const float*)p.ctx, g->fc_w, g->fc_b, B, C);
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, st, dlogits, w->fc_w, (const float*)p.y1, w->attn_w, w->attn_b,
                        p.dy1, daw_part, dab_part, S, C);
-    hipLaunchKernelGGL(colsum_kernel, dim3(8), dim3(256), 0, st, (const float*)daw_part, B, 512, 512, g->attn_w);
-    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, st, (const float*)dab_part, B, 1, 1, g->attn_b); }
+    hipLaunchKernelGGL(head_colsum_kernel, dim3(9), dim3(256), 0, st, (const float*)daw_part, (const float*)dab_part, B, g->attn_w, g->attn_b); }
     KCHECK();
 
     // ---- GRU layers, top down ----------------------------------------------------------------
@@ -432,6 +431,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         {
             TnJobs jn{};
             jn.njobs = 1;
+            if (layer == 1 && dropout_p > 0.0f) { jn.drop_p = dropout_p; jn.drop_seed = dropout_seed; }   // dy0 = mask * d(y0d)
             jn.A[0] = p.dgi; jn.lda[0] = 1536;
             jn.B[0] = w->gru_w_ih[2 * layer]; jn.B2[0] = w->gru_w_ih[2 * layer + 1]; jn.brows[0] = 768; jn.ldb[0] = in_sz;
             jn.N[0] = in_sz; jn.shift[0] = 0;
@@ -448,9 +448,6 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                 hipLaunchKernelGGL(gemm_tn_bf16x6_kernel<false>, dim3(ntiles, 1), dim3(512), TN_LDS_BYTES, st, jn, M, 1536, 1536, 1);
             }
         }
-        if (layer == 1 && dropout_p > 0.0f)
-            hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for((size_t)M * 512)), dim3(256), 0, st, p.dy0, (size_t)M * 512,
-                               dropout_p, (unsigned long long)dropout_seed);
         KCHECK();
     }
     }

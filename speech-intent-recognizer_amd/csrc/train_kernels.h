@@ -216,11 +216,29 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, size_t idx
     return (float)(unsigned)(x >> 40) * (1.0f / 16777216.0f) >= p;
 }
 
-static __global__ void dropout_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, float p,
-                               unsigned long long seed) {
+// out = dropout(in) AND the bf16x3 planes [3][n] of out (the A operand of the next layer's input projection) in one pass;
+// one thread = 8 consecutive elements (n is a multiple of 8: rows of 512)
+static __global__ __launch_bounds__(256) void dropout_split3_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                     unsigned short* __restrict__ planes, size_t n, float p,
+                                                                     unsigned long long seed) {
     const float sc = 1.0f / (1.0f - p);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = dropout_keep(seed, i, p) ? in[i] * sc : 0.0f;
+    for (size_t i8 = (size_t)blockIdx.x * 256 + threadIdx.x; i8 < n / 8; i8 += (size_t)gridDim.x * 256) {
+        const size_t i = i8 * 8;
+        float v[8];
+        *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(in + i);
+        *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(in + i + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = dropout_keep(seed, i + e, p) ? v[e] * sc : 0.0f;
+        const float4 v0 = make_float4(v[0], v[1], v[2], v[3]), v1 = make_float4(v[4], v[5], v[6], v[7]);
+        *reinterpret_cast<float4*>(out + i) = v0;
+        *reinterpret_cast<float4*>(out + i + 4) = v1;
+        uint2 h0, m0, l0, h1, m1, l1;
+        split3_quad(v0, h0, m0, l0);
+        split3_quad(v1, h1, m1, l1);
+        *reinterpret_cast<uint4*>(planes + i) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        *reinterpret_cast<uint4*>(planes + n + i) = make_uint4(m0.x, m0.y, m1.x, m1.y);
+        *reinterpret_cast<uint4*>(planes + 2 * n + i) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -349,6 +367,28 @@ static __global__ __launch_bounds__(256) void colsum_kernel(const float* __restr
     if (part == 0 && col < n_cols) out[col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// attention.weight (512 column sums of daw_part [rows][512]) and attention.bias (the sum of dab_part [rows]) in ONE launch:
+// blocks 0..7 take 64 columns each, block 8 the bias
+static __global__ __launch_bounds__(256) void head_colsum_kernel(const float* __restrict__ daw_part, const float* __restrict__ dab_part,
+                                                                  int rows, float* __restrict__ out_w, float* __restrict__ out_b) {
+    __shared__ float red[4][64];
+    const bool bias = blockIdx.x == 8;
+    const int l = threadIdx.x & 63, col = blockIdx.x * 64 + l, part = threadIdx.x >> 6;
+    float a = 0.0f;
+    if (!bias) { for (int r = part; r < rows; r += 4) a += daw_part[(size_t)r * 512 + col]; }
+    else { for (int r = threadIdx.x; r < rows; r += 256) a += dab_part[r]; }
+    if (bias) {                                   // 256 partial sums -> one value, fixed order
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    }
+    red[part][l] = a;
+    __syncthreads();
+    if (part == 0 && (!bias || l == 0)) {
+        const float v = red[0][l] + red[1][l] + red[2][l] + red[3][l];
+        if (bias) out_b[0] = v; else out_w[col] = v;
+    }
+}
+
 // the four GRU bias gradients of one layer in ONE launch: column sums of bsum_i / bsum_h [rows][1536] (blockIdx.y selects
 // the array), columns [0, 768) -> direction 0, [768, 1536) -> direction 1
 static __global__ __launch_bounds__(256) void gru_bias_colsum_kernel(const float* __restrict__ bsum_i, const float* __restrict__ bsum_h, int rows,
@@ -467,13 +507,6 @@ static __global__ void slab_reduce_jobs_kernel(SlabJobs jobs, int nslab) {
 }
 
 constexpr int GRU_BBW = 4;      // utterances per workgroup of the backward recurrence
-
-// a[i] += b[i]  /  a[i] = a[i]*mask  helpers for the layer-0 dropout backward
-static __global__ void dropout_bwd_kernel(float* __restrict__ g, size_t n, float p, unsigned long long seed) {
-    const float sc = 1.0f / (1.0f - p);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        g[i] = dropout_keep(seed, i, p) ? g[i] * sc : 0.0f;
-}
 
 // ------------------------------------------------------------------------------------------
 // backward through max-pool -> ReLU -> BatchNorm (batch statistics).
