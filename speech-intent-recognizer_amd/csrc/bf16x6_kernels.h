@@ -8,6 +8,7 @@
 // each) per 16-deep K step: 192 vs 512 matrix-pipe cycles.  Operands are split once, outside the
 // GEMM, into three bf16 planes (6 bytes per value).
 #pragma once
+#include <type_traits>
 #include "model_kernels.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -310,12 +311,12 @@ static __global__ void prep_conv_wT_bf16x3_kernel(const float* __restrict__ w, u
 //   bit 1 = input tile staged once.
 // ------------------------------------------------------------------------------------------
 // MINB = workgroups per CU the register allocation must allow (3 where the accumulators leave room)
-template <int CIN, int COUT, int PR, int PC, int OUT_MODE, int KNOCK = 0, int MINB = 2>
+template <int CIN, int COUT, int PR, int PC, int OUT_MODE, int KNOCK = 0, int MINB = 2, int PIPE = 1>
 __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpb, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp, float2* __restrict__ stats) {
     constexpr int WN = COUT / 32, WM = 4 / WN, MT = PR * PC / WM, CK = 16, PSB = 16;   // PSB: bytes between neighbouring pixels of a half-row
-    constexpr int GS = MT < 4 ? MT : 4;                     // patches per MFMA group (independent accumulators in flight)
+    constexpr int GS = MT <= 5 ? MT : 4;                    // patches per MFMA group (independent accumulators in flight)
     constexpr int TR = 8 * PR, TC = 4 * PC, TROWS = TR + 2, TCOLS = TC + 2;
     constexpr int RSB = conv_ns_row_bytes(PC), HSB = TCOLS * 16;   // row stride; offset of the second 16-byte halves inside a row
     constexpr int PLANE = TROWS * RSB;
@@ -370,35 +371,96 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
         }
         __syncthreads();
         }
+        if constexpr (PIPE && MT == GS) {
+            // One patch group per tap: the pixel fragments are software-pipelined across the taps.  The lo and hi planes of
+            // tap t + 1 are read while the MFMAs of tap t run (lo is free after the first term, hi needs a second register
+            // set), the mid plane at the top of its own tap, two terms before its first use: every ds_read_b128 has >= 4
+            // MFMAs of this wave between issue and use instead of none.  Same MFMA order per accumulator as the plain loop.
+            // NP = patches this wave computes: all MT, or only the first half where the rest starts right of the image
+            // (the last tile column of a 50-wide map: column blocks ascend with the patch index)
+            auto taps = [&](auto npc) {
+                constexpr int NP = decltype(npc)::value;
+                auto rd = [&](int tap, int p, bf16x8 (&a)[NP]) {
+                    const unsigned char* tb = ldsb + lane_off + (tap / 3) * RSB + (tap % 3) * PSB + p * PLANE;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3, g = cc * 9 + tap;
-            if (!(KNOCK & 1) && g + 1 < G) load_w(g + 1, wnext);
-            bf16x8 bfr[3];
+                    for (int i = 0; i < NP; ++i) {
+                        const int pi = wm * MT + i, poff = 8 * (pi % PR) * RSB + 4 * (pi / PR) * PSB;
+                        a[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tb + poff));
+                    }
+                };
+                bf16x8 alo[NP], ahi[NP], amid[NP], ahin[NP];
+                rd(0, 2, alo);
+                rd(0, 0, ahi);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bfr[p] = __builtin_bit_cast(bf16x8, wcur[p]);
-            const unsigned char* tapbase = ldsb + lane_off + ky * RSB + kx * PSB;
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int g = cc * 9 + tap;
+                    if (!(KNOCK & 1) && g + 1 < G) load_w(g + 1, wnext);
+                    bf16x8 bfr[3];
 #pragma unroll
-            for (int g0 = 0; g0 < MT; g0 += GS) {
-                if (g0 >= nvalid) break;
-                bf16x8 afr[GS][3];
+                    for (int p = 0; p < 3; ++p) bfr[p] = __builtin_bit_cast(bf16x8, wcur[p]);
+                    rd(tap, 1, amid);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < GS; ++i) {
-                    const int pi = wm * MT + g0 + i, poff = 8 * (pi % PR) * RSB + 4 * (pi / PR) * PSB;
+                    for (int i = 0; i < NP; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bfr[0], acc[i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tap < 8) rd(tap + 1, 2, alo);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        afr[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tapbase + p * PLANE + poff));
+                    for (int i = 0; i < NP; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bfr[2], acc[i], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(amid[i], bfr[1], acc[i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tap < 8) rd(tap + 1, 0, ahin);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(amid[i], bfr[0], acc[i], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bfr[1], acc[i], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bfr[0], acc[i], 0, 0, 0);
+                    if (tap < 8) {
+#pragma unroll
+                        for (int i = 0; i < NP; ++i) ahi[i] = ahin[i];
+                    }
+                    if (!(KNOCK & 1) && g + 1 < G) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) wcur[p] = wnext[p];
+                    }
                 }
-                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
+            };
+            if (2 * nvalid > MT || MT == 1) taps(std::integral_constant<int, MT>{});
+            else if (nvalid > 0) taps(std::integral_constant<int, (MT + 1) / 2>{});
+        } else {
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3, g = cc * 9 + tap;
+                if (!(KNOCK & 1) && g + 1 < G) load_w(g + 1, wnext);
+                bf16x8 bfr[3];
 #pragma unroll
-                    for (int i = 0; i < GS; ++i)
-                        acc[g0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][PA[t]], bfr[PB[t]], acc[g0 + i], 0, 0, 0);
-            }
-            if (!(KNOCK & 1) && g + 1 < G) {
+                for (int p = 0; p < 3; ++p) bfr[p] = __builtin_bit_cast(bf16x8, wcur[p]);
+                const unsigned char* tapbase = ldsb + lane_off + ky * RSB + kx * PSB;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) wcur[p] = wnext[p];
+                for (int g0 = 0; g0 < MT; g0 += GS) {
+                    if (g0 >= nvalid) break;
+                    bf16x8 afr[GS][3];
+#pragma unroll
+                    for (int i = 0; i < GS; ++i) {
+                        const int pi = wm * MT + g0 + i, poff = 8 * (pi % PR) * RSB + 4 * (pi / PR) * PSB;
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                            afr[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tapbase + p * PLANE + poff));
+                    }
+                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int i = 0; i < GS; ++i)
+                            acc[g0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][PA[t]], bfr[PB[t]], acc[g0 + i], 0, 0, 0);
+                }
+                if (!(KNOCK & 1) && g + 1 < G) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) wcur[p] = wnext[p];
+                }
             }
         }
     }

@@ -156,14 +156,14 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     }
     {
         SirProfScope prof(h, SIR_K_CONV2, st);
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 0, 0, 3>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), conv_ns_lds_bytes(4, 2), st,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 0, 0, 3, 0>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), conv_ns_lds_bytes(4, 2), st,
                            a1, (const unsigned short*)wcb2, bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
     }
     {
         // conv3 stores straight into the GRU input layout [B][S][c*8+h] (models.py:55-57) and writes the bf16x3 planes of
         // the first input projection's A operand beside it
         SirProfScope prof(h, SIR_K_CONV3, st);
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 1, 0, 4>), dim3((d.wp2 + 7) / 8, 1, B), dim3(256), conv_ns_lds_bytes(2, 2), st,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 1, 0, 3, 0>), dim3((d.wp2 + 7) / 8, 1, B), dim3(256), conv_ns_lds_bytes(2, 2), st,
                            a2, (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)xs);
     }
     SIR_KCHECK();
