@@ -264,7 +264,7 @@ static inline hipError_t launch_gemm_nt_bf16x6(sir_handle* h, hipStream_t st, co
 // (PMC r01: SQ_LDS_BANK_CONFLICT = 50 % of the LDS cycles of conv2) unless every row was padded, which cost the third
 // workgroup per CU.  This one is both conflict-free and a third smaller (conv2: 32,640 B against 48,960 B).
 constexpr int conv_ns_row_bytes(int PC) { return 2 * (4 * PC + 2) * 16; }
-constexpr size_t conv_ns_lds_bytes(int PR, int PC) { return (size_t)3 * (8 * PR + 2) * conv_ns_row_bytes(PC); }
+constexpr size_t conv_ns_lds_bytes(int PR, int PC, int bufs = 1) { return (size_t)bufs * 3 * (8 * PR + 2) * conv_ns_row_bytes(PC); }
 
 __device__ __forceinline__ void prep_conv_w_bf16x3_elem(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin, int cout, int idx) {
     const int total = cin * 9 * cout;
@@ -311,7 +311,7 @@ static __global__ void prep_conv_wT_bf16x3_kernel(const float* __restrict__ w, u
 //   bit 1 = input tile staged once.
 // ------------------------------------------------------------------------------------------
 // MINB = workgroups per CU the register allocation must allow (3 where the accumulators leave room)
-template <int CIN, int COUT, int PR, int PC, int OUT_MODE, int KNOCK = 0, int MINB = 2, int PIPE = 1>
+template <int CIN, int COUT, int PR, int PC, int OUT_MODE, int KNOCK = 0, int MINB = 2, int PIPE = 1, int DB = 0>
 __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpb, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp, float2* __restrict__ stats) {
@@ -347,10 +347,59 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
         for (int p = 0; p < 3; ++p) wf[p] = wp4[((size_t)p * G + g) * COUT * 2];
     };
 
+    // DB: the LDS image is double-buffered and chunk cc + 1 is staged WHILE the taps of chunk cc run -- its global loads are
+    // issued before tap 0 (into NIT float4 registers per thread), split and written to the other buffer after tap 4 -- with
+    // one barrier per chunk.  Without it every workgroup of a CU (they start together and run in lockstep) sits in its
+    // load -> split -> ds_write phase at the same time and the matrix pipe idles (timing knock-out "tile staged once").
+    constexpr int NCH = CIN / CK, NITEMS = TROWS * TCOLS * 4, NIT = (NITEMS + 255) / 256, TILEB = 3 * PLANE;
+    int goff[DB ? NIT : 1], doff[DB ? NIT : 1];             // per staging item: element offset in the image (-1: padding), byte offset in the tile (-1: none)
+    float4 pre[DB ? NIT : 1];
+    if constexpr (DB) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int idx = tid + 256 * k;
+            const int hsel = idx / (2 * TROWS * TCOLS), rem = idx - hsel * (2 * TROWS * TCOLS);
+            const int pix = rem >> 1, part = 2 * hsel + (rem & 1);
+            const int tyy = pix / TCOLS, txx = pix - tyy * TCOLS;
+            const int gy = ty0 - 1 + tyy, gx = tx0 - 1 + txx;
+            const bool item = idx < NITEMS;
+            goff[k] = (item && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (gy * W + gx) * CIN + part * 4 : -1;
+            doff[k] = item ? tyy * RSB + txx * PSB + (part >> 1) * HSB + (part & 1) * 8 : -1;
+        }
+    }
+    auto stage_load = [&](int cc) {
+#pragma unroll
+        for (int k = 0; k < (DB ? NIT : 0); ++k) {
+            pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (goff[k] >= 0) pre[k] = *reinterpret_cast<const float4*>(xb + goff[k] + cc * CK);
+        }
+    };
+    auto stage_store = [&](unsigned char* buf) {
+#pragma unroll
+        for (int k = 0; k < (DB ? NIT : 0); ++k) {
+            uint2 hh, mm, ll;
+            split3_quad(pre[k], hh, mm, ll);
+            if (doff[k] >= 0) {
+                unsigned char* d = buf + doff[k];
+                *reinterpret_cast<uint2*>(d) = hh;
+                *reinterpret_cast<uint2*>(d + PLANE) = mm;
+                *reinterpret_cast<uint2*>(d + 2 * PLANE) = ll;
+            }
+        }
+    };
+
     uint4 wcur[3], wnext[3];
     load_w(0, wcur);
-    for (int cc = 0; cc < CIN / CK; ++cc) {
-        if (!(KNOCK & 2) || cc == 0) {
+    if constexpr (DB) {
+        stage_load(0);
+        stage_store(ldsb);
+        __syncthreads();
+    }
+    for (int cc = 0; cc < NCH; ++cc) {
+        const unsigned char* tile = ldsb + (DB ? (cc & 1) * TILEB : 0);
+        unsigned char* tile_next = ldsb + ((cc + 1) & 1) * TILEB;
+        const bool stage_next = DB && cc + 1 < NCH && !(KNOCK & 2);
+        if (!DB && (!(KNOCK & 2) || cc == 0)) {
         if (cc) __syncthreads();
         for (int idx = tid; idx < TROWS * TCOLS * 4; idx += 256) {
             // 16 consecutive lanes = 8 neighbouring pixels x the two 8-byte halves of ONE 16-byte slot class (hsel): their
@@ -381,7 +430,7 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
             auto taps = [&](auto npc) {
                 constexpr int NP = decltype(npc)::value;
                 auto rd = [&](int tap, int p, bf16x8 (&a)[NP]) {
-                    const unsigned char* tb = ldsb + lane_off + (tap / 3) * RSB + (tap % 3) * PSB + p * PLANE;
+                    const unsigned char* tb = tile + lane_off + (tap / 3) * RSB + (tap % 3) * PSB + p * PLANE;
 #pragma unroll
                     for (int i = 0; i < NP; ++i) {
                         const int pi = wm * MT + i, poff = 8 * (pi % PR) * RSB + 4 * (pi / PR) * PSB;
@@ -394,6 +443,7 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int g = cc * 9 + tap;
+                    if (tap == 0 && stage_next) stage_load(cc + 1);
                     if (!(KNOCK & 1) && g + 1 < G) load_w(g + 1, wnext);
                     bf16x8 bfr[3];
 #pragma unroll
@@ -418,6 +468,7 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
                     for (int i = 0; i < NP; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bfr[1], acc[i], 0, 0, 0);
 #pragma unroll
                     for (int i = 0; i < NP; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bfr[0], acc[i], 0, 0, 0);
+                    if (tap == 4 && stage_next) stage_store(tile_next);
                     if (tap < 8) {
 #pragma unroll
                         for (int i = 0; i < NP; ++i) ahi[i] = ahin[i];
@@ -430,15 +481,17 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
             };
             if (2 * nvalid > MT || MT == 1) taps(std::integral_constant<int, MT>{});
             else if (nvalid > 0) taps(std::integral_constant<int, (MT + 1) / 2>{});
+            else if (stage_next) { stage_load(cc + 1); stage_store(tile_next); }    // a wave without pixels still stages its share
         } else {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap % 3, g = cc * 9 + tap;
+                if (tap == 0 && stage_next) stage_load(cc + 1);
                 if (!(KNOCK & 1) && g + 1 < G) load_w(g + 1, wnext);
                 bf16x8 bfr[3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) bfr[p] = __builtin_bit_cast(bf16x8, wcur[p]);
-                const unsigned char* tapbase = ldsb + lane_off + ky * RSB + kx * PSB;
+                const unsigned char* tapbase = tile + lane_off + ky * RSB + kx * PSB;
 #pragma unroll
                 for (int g0 = 0; g0 < MT; g0 += GS) {
                     if (g0 >= nvalid) break;
@@ -457,12 +510,14 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
                         for (int i = 0; i < GS; ++i)
                             acc[g0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][PA[t]], bfr[PB[t]], acc[g0 + i], 0, 0, 0);
                 }
+                if (tap == 4 && stage_next) stage_store(tile_next);
                 if (!(KNOCK & 1) && g + 1 < G) {
 #pragma unroll
                     for (int p = 0; p < 3; ++p) wcur[p] = wnext[p];
                 }
             }
         }
+        if (DB && cc + 1 < NCH) __syncthreads();             // the other buffer is complete; this one may be overwritten
     }
     const int co = wn * 32 + m;
     if (OUT_MODE == 2) {

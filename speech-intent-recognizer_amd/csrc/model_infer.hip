@@ -163,7 +163,7 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
         // conv3 stores straight into the GRU input layout [B][S][c*8+h] (models.py:55-57) and writes the bf16x3 planes of
         // the first input projection's A operand beside it
         SirProfScope prof(h, SIR_K_CONV3, st);
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 1, 0, 3, 0>), dim3((d.wp2 + 7) / 8, 1, B), dim3(256), conv_ns_lds_bytes(2, 2), st,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 1, 0, 2, 1, 1>), dim3((d.wp2 + 7) / 8, 1, B), dim3(256), conv_ns_lds_bytes(2, 2, 2), st,
                            a2, (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)xs);
     }
     SIR_KCHECK();

@@ -268,7 +268,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     }
     {
         { SirProfScope prof(h, SIR_K_T_CONV3, st);
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 2, 0, 3, 0>), dim3(d.c3fx, 1, B), dim3(256), conv_ns_lds_bytes(2, 2), st, (const float*)p.a2,
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 2, 0, 2, 1, 1>), dim3(d.c3fx, 1, B), dim3(256), conv_ns_lds_bytes(2, 2, 2), st, (const float*)p.a2,
                            (const unsigned short*)p.wcb3, (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats);
         }
         SirProfScope prof(h, SIR_K_T_BN3, st);
@@ -490,7 +490,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         {
             // data gradient = the forward kernel on the flipped / transposed prepared weights p.wcb3t (train_prep_kernel of the forward)
             SirProfScope prof(h, SIR_K_B_DGRAD3, st);
-            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<128, 64, 2, 4, 2, 0, 2>), dim3(d.c3gx, 1, B), dim3(256), conv_ns_lds_bytes(2, 4), st,
+            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<128, 64, 2, 4, 2, 0, 2, 1, 1>), dim3(d.c3gx, 1, B), dim3(256), conv_ns_lds_bytes(2, 4, 2), st,
                                (const float*)p.dz3, (const unsigned short*)p.wcb3t, (const float*)nullptr, (const float*)nullptr, p.da2, 16, d.wp2,
                                8, d.wp3, (float2*)nullptr);
         }

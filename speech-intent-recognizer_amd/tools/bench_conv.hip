@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <type_traits>
 #include <vector>
 #include "../csrc/bf16x6_kernels.h"
@@ -81,23 +82,77 @@ static void run(const char* name, int B, int H, int W) {
     float t5 = time_us(st, reps, [&] {
         hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 3>), grid, dim3(256), lds_ns, st, (const float*)dx, (const unsigned short*)wpb,
                            (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
-    auto variant = [&](auto minb, auto pipe) {
-        return time_us(st, reps, [&] {
-            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 0, decltype(minb)::value, decltype(pipe)::value>), grid, dim3(256), lds_ns, st,
+    auto variant = [&](auto minb, auto pipe, auto db) {
+        constexpr int DBv = decltype(db)::value;
+        constexpr size_t ldsv = conv_ns_lds_bytes(PR, PC, DBv ? 2 : 1);
+        auto kfn = conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, OUT_MODE, 0, decltype(minb)::value, decltype(pipe)::value, DBv>;
+        if (ldsv > 64 * 1024) CK_(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsv));
+        CK_(hipMemsetAsync(o2, 0, nout * 4, st));
+        const float t = time_us(st, reps, [&] {
+            hipLaunchKernelGGL(kfn, grid, dim3(256), ldsv, st,
                                (const float*)dx, (const unsigned short*)wpb, (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
+        if (DBv) {                                              // the double-buffered variants are new code: compare bitwise with o1
+            CK_(hipStreamSynchronize(st));
+            CK_(hipMemcpy(h2.data(), o2, nout * 4, hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (size_t i = 0; i < nout; ++i) bad += h1[i] != h2[i];
+            if (bad) printf("  !! double-buffered variant differs from the reference output in %zu values\n", bad);
+        }
+        return t;
     };
     using std::integral_constant;
-    printf("  workgroups/CU x fragment pipelining (LDS %zu B):  plain 2: %.1f  3: %.1f", lds_ns, variant(integral_constant<int, 2>{}, integral_constant<int, 0>{}),
-           variant(integral_constant<int, 3>{}, integral_constant<int, 0>{}));
-    if (PR * PC * COUT <= 512) printf("  4: %.1f", variant(integral_constant<int, 4>{}, integral_constant<int, 0>{}));
-    printf("   pipelined 2: %.1f  3: %.1f", variant(integral_constant<int, 2>{}, integral_constant<int, 1>{}), variant(integral_constant<int, 3>{}, integral_constant<int, 1>{}));
-    if (PR * PC * COUT <= 512) printf("  4: %.1f", variant(integral_constant<int, 4>{}, integral_constant<int, 1>{}));
+    using I0 = integral_constant<int, 0>; using I1 = integral_constant<int, 1>; using I2 = integral_constant<int, 2>;
+    using I3 = integral_constant<int, 3>; using I4 = integral_constant<int, 4>;
+    constexpr bool L4 = PR * PC * COUT <= 512;
+    printf("  workgroups/CU (LDS %zu B per buffer):\n", lds_ns);
+    printf("    plain                       2: %.1f  3: %.1f", variant(I2{}, I0{}, I0{}), variant(I3{}, I0{}, I0{}));
+    if (L4) printf("  4: %.1f", variant(I4{}, I0{}, I0{}));
+    printf("\n    fragments pipelined         2: %.1f  3: %.1f", variant(I2{}, I1{}, I0{}), variant(I3{}, I1{}, I0{}));
+    if (L4) printf("  4: %.1f", variant(I4{}, I1{}, I0{}));
+    printf("\n    double-buffered staging     2: %.1f  3: %.1f", variant(I2{}, I0{}, I1{}), variant(I3{}, I0{}, I1{}));
+    if (L4) printf("  4: %.1f", variant(I4{}, I0{}, I1{}));
+    printf("\n    both                        2: %.1f  3: %.1f", variant(I2{}, I1{}, I1{}), variant(I3{}, I1{}, I1{}));
+    if (L4) printf("  4: %.1f", variant(I4{}, I1{}, I1{}));
     printf(" us\n");
     printf("  gen2 knock-outs (timing only): weights once %.1f us, tile staged once %.1f us, both %.1f us\n", t3, t4, t5);
     hipFree(dx); hipFree(dw); hipFree(ds); hipFree(dt); hipFree(o1); hipFree(o2); hipFree(wpb);
 }
 
-int main() {
+// `bench_conv loop [seconds]`: the product conv2 launch back to back, for sampling clocks and power from outside
+// (rocm-smi --showclocks --showpower in a second shell) -- is the kernel running at the power cap?
+static void load_loop(double seconds) {
+    const int B = 256, H = 32, W = 100, CIN = 32, COUT = 64;
+    const size_t nx = (size_t)B * H * W * CIN, nw = (size_t)COUT * CIN * 9, nout = (size_t)B * (H / 2) * (W / 2) * COUT;
+    float *dx, *dw, *ds, *dt, *o;
+    unsigned short* wpb;
+    CK_(hipMalloc(&dx, nx * 4)); CK_(hipMalloc(&dw, nw * 4)); CK_(hipMalloc(&ds, COUT * 4)); CK_(hipMalloc(&dt, COUT * 4));
+    CK_(hipMalloc(&o, nout * 4)); CK_(hipMalloc(&wpb, nw * 6));
+    std::vector<float> hx(nx), hw(nw);
+    for (auto& v : hx) v = rand() / (float)RAND_MAX * 2.0f - 0.3f;
+    for (auto& v : hw) v = (rand() / (float)RAND_MAX - 0.5f) * 0.2f;
+    CK_(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
+    CK_(hipMemset(ds, 0, COUT * 4)); CK_(hipMemset(dt, 0, COUT * 4));
+    hipStream_t st; CK_(hipStreamCreate(&st));
+    hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((CIN * 9 * COUT + 255) / 256), dim3(256), 0, st, (const float*)dw, wpb, CIN, COUT);
+    const dim3 grid((W + 7) / 8, 1, B);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    double elapsed = 0;
+    while (elapsed < seconds) {
+        hipEventRecord(e0, st);
+        for (int i = 0; i < 1000; ++i)
+            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 0, 0, 3, 0>), grid, dim3(256), conv_ns_lds_bytes(4, 2), st, (const float*)dx,
+                               (const unsigned short*)wpb, (const float*)ds, (const float*)dt, o, H, W, H / 2, W / 2, (float2*)nullptr);
+        hipEventRecord(e1, st);
+        hipEventSynchronize(e1);
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        elapsed += ms * 1e-3;
+        printf("conv2 x1000: %.1f us per launch (t = %.2f s)\n", ms, elapsed);
+        fflush(stdout);
+    }
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "loop") { load_loop(argc > 2 ? atof(argv[2]) : 3.0); return 0; }
     run<64, 128, 2, 4, 1>("conv3", 256, 16, 50);
     run<64, 128, 2, 2, 1>("conv3, 16x8-pixel tile (4 patches per wave)", 256, 16, 50);
     run<32, 64, 4, 2, 0>("conv2", 256, 32, 100);
