@@ -51,6 +51,9 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     h->tw512 = nullptr; h->tw1024 = nullptr; h->window = nullptr; h->melw = nullptr; h->mel_desc = nullptr;
     h->status = nullptr;
     h->cluster_done = nullptr; h->cluster_stream = nullptr; h->cluster_pending = false;
+    h->cluster_seen = false; h->cluster_multi = false; h->cluster_run = 0;
+    h->cluster_always = getenv("SIR_CLUSTER_EVENTS") && atoi(getenv("SIR_CLUSTER_EVENTS")) == 1;   // A/B switch: chained mode throughout
+    if (h->cluster_always) h->cluster_multi = true;
     h->attr_gemm_v3 = h->attr_gru_quad = h->attr_gru_bwd = h->attr_tn = h->attr_wgrad = false;
     for (auto& x : h->xbufs) { x.p = nullptr; x.kind = 0; x.bytes = 0; x.epoch = 0; }
     h->xbuf_next = 0;

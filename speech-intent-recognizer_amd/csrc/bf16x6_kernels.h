@@ -374,19 +374,21 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
             if (goff[k] >= 0) pre[k] = *reinterpret_cast<const float4*>(xb + goff[k] + cc * CK);
         }
     };
-    auto stage_store = [&](unsigned char* buf) {
-#pragma unroll
-        for (int k = 0; k < (DB ? NIT : 0); ++k) {
-            uint2 hh, mm, ll;
-            split3_quad(pre[k], hh, mm, ll);
-            if (doff[k] >= 0) {
-                unsigned char* d = buf + doff[k];
-                *reinterpret_cast<uint2*>(d) = hh;
-                *reinterpret_cast<uint2*>(d + PLANE) = mm;
-                *reinterpret_cast<uint2*>(d + 2 * PLANE) = ll;
-            }
+    auto stage_store_item = [&](unsigned char* buf, int k) {
+        uint2 hh, mm, ll;
+        split3_quad(pre[k], hh, mm, ll);
+        if (doff[k] >= 0) {
+            unsigned char* d = buf + doff[k];
+            *reinterpret_cast<uint2*>(d) = hh;
+            *reinterpret_cast<uint2*>(d + PLANE) = mm;
+            *reinterpret_cast<uint2*>(d + 2 * PLANE) = ll;
         }
     };
+    auto stage_store = [&](unsigned char* buf) {
+#pragma unroll
+        for (int k = 0; k < (DB ? NIT : 0); ++k) stage_store_item(buf, k);
+    };
+    static_assert(!DB || NIT <= 8, "one staging item per tap");
 
     uint4 wcur[3], wnext[3];
     load_w(0, wcur);
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
                     for (int i = 0; i < NP; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bfr[1], acc[i], 0, 0, 0);
 #pragma unroll
                     for (int i = 0; i < NP; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bfr[0], acc[i], 0, 0, 0);
-                    if (tap == 4 && stage_next) stage_store(tile_next);
+                    if (DB && tap >= 1 && tap <= NIT && stage_next) stage_store_item(tile_next, tap - 1);   // one item per tap: the split's VALU work rides between the MFMAs
                     if (tap < 8) {
 #pragma unroll
                         for (int i = 0; i < NP; ++i) ahi[i] = ahin[i];
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
                         for (int i = 0; i < GS; ++i)
                             acc[g0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][PA[t]], bfr[PB[t]], acc[g0 + i], 0, 0, 0);
                 }
-                if (tap == 4 && stage_next) stage_store(tile_next);
+                if (DB && tap >= 1 && tap <= NIT && stage_next) stage_store_item(tile_next, tap - 1);
                 if (!(KNOCK & 1) && g + 1 < G) {
 #pragma unroll
                     for (int p = 0; p < 3; ++p) wcur[p] = wnext[p];

@@ -64,10 +64,11 @@ struct sir_handle {
     // guarantees that within ONE launch, but two such launches on different streams interleave their dispatch and, once
     // their workgroups outnumber the CUs, can fill the chip with partial clusters that wait for each other for ever (seen
     // with 2 processes x 2 streams on one GPU: spin time-outs).  Launches of cluster kernels issued through this handle are
-    // therefore chained: one on another stream first waits for the previous one's completion event.
+    // therefore chained: one on another stream first waits for the previous one's completion event (sir_cluster_enter).
     hipEvent_t cluster_done;
-    hipStream_t cluster_stream;
-    bool cluster_pending;
+    hipStream_t cluster_stream;        // stream of the latest cluster launch (compared, never dereferenced)
+    bool cluster_pending, cluster_seen, cluster_multi, cluster_always;
+    int cluster_run;                   // chained mode: launches in a row that came from cluster_stream
     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) latches, per handle = per device (a process-wide static would skip
     // the second device of a process that drives several)
     bool attr_gemm_v3, attr_gru_quad, attr_gru_bwd, attr_tn, attr_wgrad;
@@ -101,16 +102,33 @@ static inline int sir_xbuf_epoch(sir_handle* h, hipStream_t st, void* xbuf, int 
     return SIR_OK;
 }
 
-// bracket of a cluster-kernel launch (see sir_handle::cluster_done)
+// bracket of a cluster-kernel launch (see sir_handle::cluster_done).  The completion event costs the stream a ~6 us bubble
+// per launch (the next kernel waits for the marker packet), so it is only recorded while launches really come from more
+// than one stream: a handle starts in single-stream mode, the first launch from a second stream drains the device once
+// and switches to chained mode, 64 launches in a row from one stream switch back.
 static inline int sir_cluster_enter(sir_handle* h, hipStream_t st) {
+    if (!h->cluster_multi) {
+        if (h->cluster_seen && h->cluster_stream != st) {
+            if (hipDeviceSynchronize() != hipSuccess) return SIR_EHIP;
+            h->cluster_multi = true;
+            h->cluster_pending = false;
+            h->cluster_run = 0;
+        }
+        return SIR_OK;
+    }
     if (h->cluster_pending && h->cluster_stream != st)
         if (hipStreamWaitEvent(st, h->cluster_done, 0) != hipSuccess) return SIR_EHIP;
     return SIR_OK;
 }
 static inline int sir_cluster_leave(sir_handle* h, hipStream_t st) {
-    if (hipEventRecord(h->cluster_done, st) != hipSuccess) return SIR_EHIP;
+    if (h->cluster_multi) {
+        if (hipEventRecord(h->cluster_done, st) != hipSuccess) return SIR_EHIP;
+        h->cluster_pending = true;
+        h->cluster_run = (h->cluster_stream == st) ? h->cluster_run + 1 : 0;
+        if (h->cluster_run >= 64 && !h->cluster_always) { h->cluster_multi = false; h->cluster_pending = false; }
+    }
     h->cluster_stream = st;
-    h->cluster_pending = true;
+    h->cluster_seen = true;
     return SIR_OK;
 }
 
