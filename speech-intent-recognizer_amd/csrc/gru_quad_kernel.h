@@ -20,6 +20,7 @@
 #pragma once
 #include "bf16x6_kernels.h"
 
+typedef unsigned int gq_u32x4 __attribute__((ext_vector_type(4)));   // native vector: usable as an inline-asm operand
 constexpr int GQ_NU = 16;                 // utterances per cluster (the MFMA N dimension)
 constexpr int GQ_UQ = 64;                 // hidden units per workgroup
 constexpr int GQ_THREADS = 256;
@@ -203,10 +204,16 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
             const unsigned hh_[4] = {ph.x & 0xFFFFu, ph.x >> 16, ph.y & 0xFFFFu, ph.y >> 16};
             const unsigned mm_[4] = {pm.x & 0xFFFFu, pm.x >> 16, pm.y & 0xFFFFu, pm.y >> 16};
             const unsigned ll_[4] = {pl.x & 0xFFFFu, pl.x >> 16, pl.y & 0xFFFFu, pl.y >> 16};
+            unsigned long long gr[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                __hip_atomic_store(gs + j, tag | ((unsigned long long)hh_[j] << 32) | ((unsigned long long)mm_[j] << 16) | ll_[j],
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int j = 0; j < 4; ++j) gr[j] = tag | ((unsigned long long)hh_[j] << 32) | ((unsigned long long)mm_[j] << 16) | ll_[j];
+            // the lane's four granules are 32 contiguous bytes: two 16-byte write-through stores (sc1 = what a relaxed agent-scope
+            // atomic store compiles to) instead of four 8-byte ones -- half the store instructions and memory transactions
+            // in front of the poll.  Every granule carries its own tag, so nothing depends on the pair landing together.
+            const gq_u32x4 g01 = {(unsigned)gr[0], (unsigned)(gr[0] >> 32), (unsigned)gr[1], (unsigned)(gr[1] >> 32)};
+            const gq_u32x4 g23 = {(unsigned)gr[2], (unsigned)(gr[2] >> 32), (unsigned)gr[3], (unsigned)(gr[3] >> 32)};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1"
+                         :: "v"(gs), "v"(g01), "v"(g23) : "memory");
         }
         // ---- receive the other three quarters' values of this step into the next-parity planes ------------
         if (step + 1 < S && !(dbg & 4)) {
@@ -217,12 +224,26 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
             const unsigned long long want = (unsigned long long)((epoch << 9) | (unsigned)(step + 1));
             const unsigned long long* src0 = xc + ((size_t)(step & 1) * 4 * GQ_NU + rn) * GQ_UQ + ru4 * 4;
             for (;;) {
-#pragma unroll
-                for (int qi = 0; qi < 3; ++qi) {
-                    const int qs = qi + (qi >= q ? 1 : 0);   // source quarter != q
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        v[qi][j] = __hip_atomic_load(src0 + (size_t)qs * GQ_NU * GQ_UQ + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                {
+                    // six 16-byte loads (sc1: past the non-coherent caches, like the relaxed agent-scope atomic loads they replace),
+                    // issued back to back, one wait
+                    const unsigned long long* p0 = src0 + (size_t)(q <= 0 ? 1 : 0) * GQ_NU * GQ_UQ;
+                    const unsigned long long* p1 = src0 + (size_t)(q <= 1 ? 2 : 1) * GQ_NU * GQ_UQ;
+                    const unsigned long long* p2 = src0 + (size_t)(q <= 2 ? 3 : 2) * GQ_NU * GQ_UQ;
+                    gq_u32x4 a0, a1, b0, b1, c0, c1;
+                    asm volatile("global_load_dwordx4 %0, %6, off sc1\n\t"
+                                 "global_load_dwordx4 %1, %6, off offset:16 sc1\n\t"
+                                 "global_load_dwordx4 %2, %7, off sc1\n\t"
+                                 "global_load_dwordx4 %3, %7, off offset:16 sc1\n\t"
+                                 "global_load_dwordx4 %4, %8, off sc1\n\t"
+                                 "global_load_dwordx4 %5, %8, off offset:16 sc1\n\t"
+                                 "s_waitcnt vmcnt(0)"
+                                 : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1), "=&v"(c0), "=&v"(c1)
+                                 : "v"(p0), "v"(p1), "v"(p2) : "memory");
+                    auto u64 = [](unsigned lo, unsigned hi) { return (unsigned long long)lo | ((unsigned long long)hi << 32); };
+                    v[0][0] = u64(a0.x, a0.y); v[0][1] = u64(a0.z, a0.w); v[0][2] = u64(a1.x, a1.y); v[0][3] = u64(a1.z, a1.w);
+                    v[1][0] = u64(b0.x, b0.y); v[1][1] = u64(b0.z, b0.w); v[1][2] = u64(b1.x, b1.y); v[1][3] = u64(b1.z, b1.w);
+                    v[2][0] = u64(c0.x, c0.y); v[2][1] = u64(c0.z, c0.w); v[2][2] = u64(c1.x, c1.y); v[2][3] = u64(c1.z, c1.w);
                 }
                 bool ok = true;
 #pragma unroll
