@@ -29,7 +29,7 @@ constexpr int GQ_PLANEB = GQ_NU * GQ_ROWB;
 constexpr int GQ_BUFB = 3 * GQ_PLANEB;    // one parity buffer: 25,344 B
 constexpr size_t GQ_LDS_BYTES = 2 * (size_t)GQ_BUFB;
 constexpr unsigned GQ_SPIN_LIMIT = 1u << 22;
-constexpr size_t GQ_XBUF_PER_CLUSTER = (size_t)2 * 4 * GQ_NU * GQ_UQ * 8;   // [parity][quarter][utterance][unit] granules
+constexpr size_t GQ_XBUF_PER_CLUSTER = (size_t)2 * 4 * GQ_NU * GQ_UQ * 8;   // [parity][quarter][wave][store 0 | 1][lane][2] granules (producer-thread order)
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -136,8 +136,10 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     };
     load_gi(dir ? S - 1 : 0, gin);
     const int frag_off = n * GQ_ROWB + kg * 16;              // this lane's chunk inside a k-step of an h plane row
-    // receive role: thread = (utterance rn, 4-unit group ru4) of each of the three other quarters
-    const int rn = tid >> 4, ru4 = tid & 15;
+    // receive role: thread t fetches what thread t of each of the three other quarters stored (same utterance n, same units
+    // relative to the quarter): granule order in the buffer is [wave][store 0 | store 1][lane][2], so that every store and
+    // every poll instruction covers 1 KB of consecutive bytes = 16 whole cache lines
+    const int xoff = wv * 256 + lane * 2;                    // granule offset of this thread inside a (parity, quarter) block
     bool timed_out = false;
 
     for (int step = 0; step < S; ++step) {
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
             *reinterpret_cast<uint2*>(d + 2 * GQ_PLANEB) = pl;
         }
         if (!(dbg & 4) && !((dbg & 8) && q == 3)) {
-            unsigned long long* gs = xc + (((size_t)(step & 1) * 4 + q) * GQ_NU + n) * GQ_UQ + (u0 - q * GQ_UQ);
+            unsigned long long* gs = xc + ((size_t)(step & 1) * 4 + q) * (GQ_NU * GQ_UQ) + xoff;
             const unsigned long long tag = (unsigned long long)((epoch << 9) | (unsigned)(step + 1)) << 48;
             const unsigned hh_[4] = {ph.x & 0xFFFFu, ph.x >> 16, ph.y & 0xFFFFu, ph.y >> 16};
             const unsigned mm_[4] = {pm.x & 0xFFFFu, pm.x >> 16, pm.y & 0xFFFFu, pm.y >> 16};
@@ -207,12 +209,12 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
             unsigned long long gr[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) gr[j] = tag | ((unsigned long long)hh_[j] << 32) | ((unsigned long long)mm_[j] << 16) | ll_[j];
-            // the lane's four granules are 32 contiguous bytes: two 16-byte write-through stores (sc1 = what a relaxed agent-scope
+            // the lane's four granules go out as two 16-byte write-through stores (sc1 = what a relaxed agent-scope
             // atomic store compiles to) instead of four 8-byte ones -- half the store instructions and memory transactions
             // in front of the poll.  Every granule carries its own tag, so nothing depends on the pair landing together.
             const gq_u32x4 g01 = {(unsigned)gr[0], (unsigned)(gr[0] >> 32), (unsigned)gr[1], (unsigned)(gr[1] >> 32)};
             const gq_u32x4 g23 = {(unsigned)gr[2], (unsigned)(gr[2] >> 32), (unsigned)gr[3], (unsigned)(gr[3] >> 32)};
-            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1"
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:1024 sc1"
                          :: "v"(gs), "v"(g01), "v"(g23) : "memory");
         }
         // ---- receive the other three quarters' values of this step into the next-parity planes ------------
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
             unsigned long long v[3][4];
             unsigned spins = 0;
             const unsigned long long want = (unsigned long long)((epoch << 9) | (unsigned)(step + 1));
-            const unsigned long long* src0 = xc + ((size_t)(step & 1) * 4 * GQ_NU + rn) * GQ_UQ + ru4 * 4;
+            const unsigned long long* src0 = xc + (size_t)(step & 1) * 4 * (GQ_NU * GQ_UQ) + xoff;
             for (;;) {
                 {
                     // six 16-byte loads (sc1: past the non-coherent caches, like the relaxed agent-scope atomic loads they replace),
@@ -232,11 +234,11 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
                     const unsigned long long* p2 = src0 + (size_t)(q <= 2 ? 3 : 2) * GQ_NU * GQ_UQ;
                     gq_u32x4 a0, a1, b0, b1, c0, c1;
                     asm volatile("global_load_dwordx4 %0, %6, off sc1\n\t"
-                                 "global_load_dwordx4 %1, %6, off offset:16 sc1\n\t"
+                                 "global_load_dwordx4 %1, %6, off offset:1024 sc1\n\t"
                                  "global_load_dwordx4 %2, %7, off sc1\n\t"
-                                 "global_load_dwordx4 %3, %7, off offset:16 sc1\n\t"
+                                 "global_load_dwordx4 %3, %7, off offset:1024 sc1\n\t"
                                  "global_load_dwordx4 %4, %8, off sc1\n\t"
-                                 "global_load_dwordx4 %5, %8, off offset:16 sc1\n\t"
+                                 "global_load_dwordx4 %5, %8, off offset:1024 sc1\n\t"
                                  "s_waitcnt vmcnt(0)"
                                  : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1), "=&v"(c0), "=&v"(c1)
                                  : "v"(p0), "v"(p1), "v"(p2) : "memory");
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
                 rm.y = (unsigned)((v[qi][2] >> 16) & 0xFFFFu) | ((unsigned)((v[qi][3] >> 16) & 0xFFFFu) << 16);
                 rl.x = (unsigned)(v[qi][0] & 0xFFFFu) | ((unsigned)(v[qi][1] & 0xFFFFu) << 16);
                 rl.y = (unsigned)(v[qi][2] & 0xFFFFu) | ((unsigned)(v[qi][3] & 0xFFFFu) << 16);
-                unsigned char* d = hnb + rn * GQ_ROWB + (qs * GQ_UQ + ru4 * 4) * 2;
+                unsigned char* d = hnb + n * GQ_ROWB + (qs * GQ_UQ + (u0 - q * GQ_UQ)) * 2;
                 *reinterpret_cast<uint2*>(d) = rh;
                 *reinterpret_cast<uint2*>(d + GQ_PLANEB) = rm;
                 *reinterpret_cast<uint2*>(d + 2 * GQ_PLANEB) = rl;
