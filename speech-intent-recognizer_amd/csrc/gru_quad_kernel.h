@@ -29,6 +29,7 @@ constexpr int GQ_PLANEB = GQ_NU * GQ_ROWB;
 constexpr int GQ_BUFB = 3 * GQ_PLANEB;    // one parity buffer: 25,344 B
 constexpr size_t GQ_LDS_BYTES = 2 * (size_t)GQ_BUFB;
 constexpr unsigned GQ_SPIN_LIMIT = 1u << 22;
+constexpr int GQ_POLL_DELAY = 16;          // x 64 cycles between the granule stores and the first poll round (see the poll loop)
 constexpr size_t GQ_XBUF_PER_CLUSTER = (size_t)2 * 4 * GQ_NU * GQ_UQ * 8;   // [parity][quarter][wave][store 0 | 1][lane][2] granules (producer-thread order)
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -225,6 +226,11 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
             unsigned spins = 0;
             const unsigned long long want = (unsigned long long)((epoch << 9) | (unsigned)(step + 1));
             const unsigned long long* src0 = xc + (size_t)(step & 1) * 4 * (GQ_NU * GQ_UQ) + xoff;
+            // The partners' granules need ~0.8 us to become visible.  A poll round issued at once reaches memory before them,
+            // comes back stale after ~0.7 us and the round that succeeds starts only then; a first round that leaves ~0.45 us
+            // later is the one that succeeds (measured per layer launch: 106 us with no delay, 102.4 at 8 x 64 cycles,
+            // 100.4 at 16, 102 at 20, 107 at 24).  dbg bits 8-12 add to the delay (experiments).
+            for (int i = 0; i < GQ_POLL_DELAY + ((dbg >> 8) & 31); ++i) __builtin_amdgcn_s_sleep(1);
             for (;;) {
                 {
                     // six 16-byte loads (sc1: past the non-coherent caches, like the relaxed agent-scope atomic loads they replace),
