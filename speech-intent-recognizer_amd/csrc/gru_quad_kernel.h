@@ -12,10 +12,11 @@
 //     arithmetic is lane-local;
 //   * h lives in LDS as three bf16 planes [utterance][k] (double-buffered by step parity, rows padded to
 //     528 B); every workgroup needs all 256 units, so after each step the four quarters exchange their
-//     64 x 16 new values through global memory: one 8-byte granule per value = {tag = step + 1 (16 bit),
-//     hi, mid, lo bf16} written by ONE agent-scope relaxed 64-bit store and polled with agent-scope relaxed
-//     loads until the tag matches (recipe R2 of cdna_hip_programming.md G16, as in gru_pair_kernel: the
-//     data is the flag).  Granule buffers alternate by step parity and are zeroed before every launch.
+//     64 x 16 new values through global memory: one 8-byte granule per value = {16-bit tag = launch epoch + step + 1,
+//     hi, mid, lo bf16}, written write-through (sc1, the code of an agent-scope relaxed atomic store) two granules per
+//     16-byte store, and polled with 16-byte sc1 loads until every tag matches (recipe R2 of cdna_hip_programming.md
+//     G16: the data is the flag -- each granule carries its own tag, so nothing depends on a pair landing together).
+//     Granule buffers alternate by step parity; a buffer is zeroed when new to the handle, not per launch.
 // Results differ from the fp32-FMA kernel only by the bf16x6 product rounding (~2^-24 relative per product).
 #pragma once
 #include "bf16x6_kernels.h"
@@ -307,7 +308,13 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     }
 }
 
-// Measured with timing knock-outs (dbg): of the ~5 us step, MFMA phase 1.3 us, gates + stores 0.5 us, exchange ~2.1 us.  A
+// Measured with timing knock-outs (dbg), current kernel (103 us per layer launch = 4.1 us per step): without the MFMAs
+// 66 us (MFMA phase 1.5 us), without the exchange 65 us (hand-off 1.5 us: stores + one ~0.7 us poll round + 0.4 us of
+// waiting), with neither 29 us (gates, LDS planes, barrier, output stores: 1.2 us).  The hand-off was 2.1 us while a lane
+// issued four 8-byte stores and twelve 8-byte polls into a [utterance][unit] granule layout (each instruction touched
+// 32 cache lines in 16-byte pieces): 126 -> 120 us with 16-byte accesses, -> 108 us with the producer-thread layout,
+// -> 103 us with the delayed first poll.
+// Earlier measurements (8-byte granule accesses): of the ~5 us step, MFMA phase 1.3 us, gates + stores 0.5 us, exchange ~2.1 us.  A
 // poll round issued with NO granule stores ahead of it in the same wave costs 0.6 us; behind the wave's own write-through
 // stores it costs 2.1 us -- but the remote stores need about that long to become visible anyway.  Tried and removed: a
 // dedicated publisher wave (re-reads the workgroup's values from LDS and stores all 1024 granules) with the other three
