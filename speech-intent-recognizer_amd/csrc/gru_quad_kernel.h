@@ -77,7 +77,8 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     // yplanes (optional): bf16x3 planes [3][B * S][512] of y, the A operand of the next layer's input projection
     // dbg (timing experiments only, results invalid): bit 0 = do not wait for the granules, bit 1 = skip the MFMAs,
     // bit 2 = skip publish + receive; fault injection for the status-word test: bit 3 = quarter 3 never publishes (its
-    // peers time out), bit 4 = spin limit 4096 instead of 2^22 (so that the injected timeout takes milliseconds)
+    // peers time out), bit 4 = spin limit 4096 instead of 2^22 (so that the injected timeout takes milliseconds);
+    // bits 8-12 = extra delay of the first poll round in units of 64 cycles (results stay valid)
     extern __shared__ __attribute__((aligned(16))) unsigned char qlds[];
     const int q = blockIdx.x, cluster = blockIdx.y;
     const int dir = cluster & 1, grp = cluster >> 1;
