@@ -1,0 +1,272 @@
+// conv 3x3 (pad 1) as Winograd F(2x2, 3x3) on the bf16 matrix cores, bf16x6 products (fp32 accuracy), for the
+// 32 -> 64 channel block (conv2): 16 products per 2x2 output tile and channel pair instead of 36, and the 2x2
+// output tile IS the max-pool window, so BN + ReLU + pool are a maximum over four accumulators.
+//
+//   Y = A^T [ (G g G^T) . (B^T d B) ] A        d: 4x4 input patch, g: 3x3 taps, Y: 2x2 outputs, "." elementwise,
+//   summed over the input channels inside the bracket -- i.e. per frequency f = (i, j) of the 4x4 transform one GEMM
+//   M_f[tile][cout] = sum_cin V_f[tile][cin] U_f[cin][cout] on MFMA, then the (linear) inverse transform on the accumulators.
+//
+// Workgroup = 256 threads = one block of 32 tiles (16 tile rows x 2 tile columns = 32 x 4 output pixels) x all 64 output
+// channels, one 16-input-channel chunk at a time:
+//   staging   thread (tile, 4-channel group, half fh) loads the 3 x 4 patch pixels its two transform rows need (float4 =
+//             4 channels), applies B^T . B, splits the 8 results into bf16x3 and writes them to LDS as V[plane][f][half][tile][8 ch]
+//             (a (plane, f) block = 1 KB: the first 8-channel halves of the 32 tiles, then the second halves -- one MFMA A
+//             fragment = one ds_read_b128 per lane over 512 contiguous bytes, conflict-free like the direct kernel's image);
+//   MFMA      wave (wn, wf) = output-channel slice 32 wn.., frequencies 8 wf .. 8 wf + 7 (transform rows i = 2 wf, 2 wf + 1).
+//             Weights U_f are prepared by prep_conv_w_wino_bf16x3_kernel as wpb[plane][chunk * 16 + f][cout][16 ch] (the
+//             layout of the direct kernel with "frequency" for "tap") and streamed one frequency ahead.  Column inverse
+//             transform on the fly: W[i][0] = M[i][0] + M[i][1] + M[i][2], W[i][1] = M[i][1] - M[i][2] - M[i][3]:
+//             j = 0 accumulates straight into W[i][0] and j = 3 straight into W[i][1] (its weights are stored NEGATED),
+//             j = 1, 2 go through a scratch accumulator and two VALU adds;
+//   epilogue  row inverse transform per wave (Y[0][b] = W[0][b] + W[1][b] + W[2][b], Y[1][b] = W[1][b] - W[2][b] - W[3][b],
+//             the wf = 1 waves hand their partial sums to the wf = 0 waves through LDS), then BN + ReLU + 2x2 max
+//             (OUT_MODE 0: pooled NHWC store) or the raw 2x2 outputs + per-workgroup channel statistics (OUT_MODE 2).
+// Same contract as conv3x3_bf16x6_ns_kernel (NHWC fp32 in, folded scale / shift, float2 statistics partials per workgroup).
+#pragma once
+#include "bf16x6_kernels.h"
+
+constexpr int WINO_LDS_BYTES = 3 * 16 * 1024;                 // V planes of one chunk; reused for the wf = 1 -> wf = 0 hand-over (32 KB)
+
+// U = G g G^T of every (cout, cin) pair as bf16x3 planes: wpb[plane][(ci / 16) * 16 + f][co][ci % 16], f = 4 i + j;
+// column j = 3 negated (see the MFMA phase).  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__device__ __forceinline__ void prep_conv_w_wino_bf16x3_elem(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin, int cout, int idx) {
+    const int total = cin * 16 * cout;
+    if (idx >= total) return;
+    const int e = idx & 15, co = (idx >> 4) % cout, g = (idx >> 4) / cout;
+    const int ci = (g / 16) * 16 + e, f = g % 16, i = f >> 2, j = f & 3;
+    const float* gk = w + ((size_t)co * cin + ci) * 9;
+    const float Gm[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+    float u = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float t = 0.0f;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) t = fmaf(gk[k * 3 + l], Gm[j][l], t);
+        u = fmaf(Gm[i][k], t, u);
+    }
+    if (j == 3) u = -u;
+    unsigned short h, m, l;
+    split3(u, h, m, l);
+    wpb[idx] = h;
+    wpb[(size_t)total + idx] = m;
+    wpb[2 * (size_t)total + idx] = l;
+}
+static __global__ void prep_conv_w_wino_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin, int cout) {
+    prep_conv_w_wino_bf16x3_elem(w, wpb, cin, cout, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// grid (ceil(ceil(W / 2) / 2), ceil(H / 32), B): one block of 16 x 2 tiles per workgroup
+// KNOCK (tools/bench_conv.hip timing experiments, results invalid; 0 in the product): bit 0 = no patch loads, bit 1 = no
+// transform / split / LDS writes, bit 2 = no MFMAs, bit 3 = no output stores
+template <int CIN, int COUT, int OUT_MODE, int MINB = 3, int XCD_REMAP = 1, int KNOCK = 0>
+__global__ __launch_bounds__(256, MINB) void conv3x3_wino_bf16x6_kernel(
+    const float* __restrict__ x, const unsigned short* __restrict__ wpb, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp, float2* __restrict__ stats) {
+    constexpr int NCH = CIN / 16, G = NCH * 16;
+    constexpr int PLB = 16 * 1024, FB = 1024;                // bytes per plane / per frequency block
+    static_assert(COUT == 64 && CIN % 16 == 0, "two 32-channel slices x two frequency halves = four waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char wl[];
+    // Workgroups are dealt to the 8 XCDs round robin (linear id % 8) and each XCD has its own L2: renumber them so that the
+    // blocks of one utterance (which share two halo columns with their neighbours) run on ONE XCD, one after the other
+    int bxi = blockIdx.x, bzi = blockIdx.z;
+    {
+        const unsigned nx = gridDim.x, total = nx * gridDim.z, lin = blockIdx.z * nx + blockIdx.x;
+        if (XCD_REMAP && gridDim.y == 1 && total % 8 == 0) {
+            const unsigned v = (lin & 7) * (total >> 3) + (lin >> 3);
+            bxi = v % nx; bzi = v / nx;
+        }
+    }
+    const int b = bzi, tx0 = 2 * bxi, ty0 = 16 * blockIdx.y;                     // first tile column / row of the block
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wn = wv & 1, wf = wv >> 1;                     // channel slice, frequency half (== staging half: tid >> 7)
+    const int m = lane & 31, h = lane >> 5;
+
+    // staging role: tile sm = (row sm >> 1, column sm & 1) of the block, channels 4 part .. 4 part + 3 of the chunk.  A wave
+    // takes ONE 8-channel half (part >> 1) of all 32 tiles: its ds_write_b64 covers 512 contiguous bytes
+    const int part = (tid & 1) + 2 * ((tid >> 6) & 1), sm = (tid >> 1) & 31;
+    const int gy0 = 2 * (ty0 + (sm >> 1)) - 1 + wf;          // first of the three patch rows this half needs (rows wf .. wf + 2)
+    const int gx0 = 2 * (tx0 + (sm & 1)) - 1;
+    // patch addresses as 32-bit element offsets row_off[rr] + col_off[j] from one base (clamped into the image: every
+    // load is unconditional and in range, padding is a select afterwards -- a bounds branch per load had the compiler
+    // spill twelve 64-bit addresses and wait for each reload, one load in flight at a time: 279 us instead of 130)
+    const float* xb = x + (size_t)b * H * W * CIN + part * 4;
+    int row_off[3], col_off[4];
+    bool row_ok[3], col_ok[4];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+        const int gy = gy0 + rr;
+        row_ok[rr] = gy >= 0 && gy < H;
+        row_off[rr] = min(max(gy, 0), H - 1) * W * CIN;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int gx = gx0 + j;
+        col_ok[j] = gx >= 0 && gx < W;
+        col_off[j] = min(max(gx, 0), W - 1) * CIN;
+    }
+    unsigned char* vdst = wl + (part >> 1) * 512 + sm * 16 + (part & 1) * 8;     // + plane * PLB + f * FB
+
+    const uint4* wp4 = reinterpret_cast<const uint4*>(wpb) + (size_t)(wn * 32 + m) * 2 + h;     // + ((p * G + g) * COUT) * 2
+    auto load_w = [&](int g, uint4 (&wq)[3]) {                // 32-bit offsets from one base, no branch (callers clamp g)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wq[p] = wp4[(p * G + g) * (COUT * 2)];
+    };
+    f32x16 Wa[2][2];                                         // [transform row of this wave][b]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Wa[i][c][r] = 0.0f;
+    // weight fragments are fetched WPF frequencies ahead of their MFMAs: one frequency is only ~200 cycles of matrix work,
+    // an L2 hit takes several hundred (timing knock-outs: with one frequency of lead the kernel's skeleton alone took 44 us)
+    constexpr int WPF = MINB >= 3 ? 2 : 4;                   // divides 8: the register slot ff % WPF is the same in every chunk
+    uint4 wq[WPF][3];
+#pragma unroll
+    for (int k = 0; k < WPF; ++k) load_w(8 * wf + k, wq[k]);
+
+    for (int cc = 0; cc < NCH; ++cc) {
+        if (cc) __syncthreads();                             // the previous chunk's fragments have been read
+        {
+            float4 L[3][4];
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    L[rr][j] = (KNOCK & 1) ? make_float4(1.f, 2.f, 3.f, (float)(rr + j)) : *reinterpret_cast<const float4*>(xb + (row_off[rr] + col_off[j] + cc * 16));
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (!(row_ok[rr] && col_ok[j])) L[rr][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            // rows of B^T d: half 0 (patch rows 0,1,2 loaded) R0 = d0 - d2, R1 = d1 + d2; half 1 (rows 1,2,3) R2 = d2 - d1, R3 = d1 - d3
+            float4 R[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 a0 = L[0][j], a1 = L[1][j], a2 = L[2][j];
+                if (wf == 0) {
+                    R[0][j] = make_float4(a0.x - a2.x, a0.y - a2.y, a0.z - a2.z, a0.w - a2.w);
+                    R[1][j] = make_float4(a1.x + a2.x, a1.y + a2.y, a1.z + a2.z, a1.w + a2.w);
+                } else {
+                    R[0][j] = make_float4(a1.x - a0.x, a1.y - a0.y, a1.z - a0.z, a1.w - a0.w);
+                    R[1][j] = make_float4(a0.x - a2.x, a0.y - a2.y, a0.z - a2.z, a0.w - a2.w);
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < ((KNOCK & 2) ? 0 : 2); ++ii) {
+                const float4 r0 = R[ii][0], r1 = R[ii][1], r2 = R[ii][2], r3 = R[ii][3];
+                const float4 V[4] = {make_float4(r0.x - r2.x, r0.y - r2.y, r0.z - r2.z, r0.w - r2.w),
+                                     make_float4(r1.x + r2.x, r1.y + r2.y, r1.z + r2.z, r1.w + r2.w),
+                                     make_float4(r2.x - r1.x, r2.y - r1.y, r2.z - r1.z, r2.w - r1.w),
+                                     make_float4(r1.x - r3.x, r1.y - r3.y, r1.z - r3.z, r1.w - r3.w)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint2 hh, mm, ll;
+                    split3_quad(V[j], hh, mm, ll);
+                    unsigned char* d = vdst + (4 * (2 * wf + ii) + j) * FB;
+                    *reinterpret_cast<uint2*>(d) = hh;
+                    *reinterpret_cast<uint2*>(d + PLB) = mm;
+                    *reinterpret_cast<uint2*>(d + 2 * PLB) = ll;
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned char* afrag = wl + h * 512 + m * 16 + 8 * wf * FB;
+#pragma unroll
+        for (int ff = 0; ff < 8; ++ff) {
+            const int il = ff >> 2, j = ff & 3;
+            // this wave's frequency sequence: 8 wf + 0..7 of chunk 0, then of chunk 1, ...; the one WPF steps ahead (clamped: a
+            // redundant reload past the end)
+            const int seq = cc * 8 + ff + WPF, gnext = min((seq >> 3) * 16 + 8 * wf + (seq & 7), G - 1);
+            bf16x8 a[3], bq[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(afrag + p * PLB + ff * FB));
+                bq[p] = __builtin_bit_cast(bf16x8, wq[ff % WPF][p]);
+            }
+            load_w(gnext, wq[ff % WPF]);
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
+            if (KNOCK & 4) {
+                Wa[il][j & 1][0] += __builtin_bit_cast(float4, a[0]).x * __builtin_bit_cast(float4, bq[1]).y + __builtin_bit_cast(float4, a[2]).x + __builtin_bit_cast(float4, bq[2]).x + __builtin_bit_cast(float4, a[1]).x + __builtin_bit_cast(float4, bq[0]).x;
+            } else if (j == 0 || j == 3) {                   // one target, sign folded into the weights: accumulate in place
+                f32x16& acc = Wa[il][j == 0 ? 0 : 1];
+#pragma unroll
+                for (int t = 0; t < 6; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]], bq[PB[t]], acc, 0, 0, 0);
+            } else {
+                f32x16 M;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) M[r] = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 6; ++t) M = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]], bq[PB[t]], M, 0, 0, 0);
+                Wa[il][0] += M;
+                if (j == 1) Wa[il][1] += M; else Wa[il][1] -= M;
+            }
+        }
+    }
+
+    // row inverse transform, partial per wave: wf = 0 holds rows 0, 1; wf = 1 rows 2, 3
+    f32x16 Y[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (wf == 0) { Y[0][c] = Wa[0][c] + Wa[1][c]; Y[1][c] = Wa[1][c]; }
+        else         { Y[0][c] = Wa[0][c];            Y[1][c] = -Wa[0][c] - Wa[1][c]; }
+    }
+    __syncthreads();                                         // all fragment reads done: the V area becomes the hand-over buffer
+    float4* hand = reinterpret_cast<float4*>(wl) + (size_t)wn * (4 * 4 * 64);   // [wn][o][r / 4][lane] float4
+    if (wf == 1) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                hand[(o * 4 + q) * 64 + lane] = make_float4(Y[o >> 1][o & 1][4 * q], Y[o >> 1][o & 1][4 * q + 1], Y[o >> 1][o & 1][4 * q + 2], Y[o >> 1][o & 1][4 * q + 3]);
+    }
+    __syncthreads();
+    float ssum = 0.0f, ssq = 0.0f;
+    const int co = wn * 32 + m;
+    if (wf == 0) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = hand[(o * 4 + q) * 64 + lane];
+                Y[o >> 1][o & 1][4 * q] += v.x; Y[o >> 1][o & 1][4 * q + 1] += v.y;
+                Y[o >> 1][o & 1][4 * q + 2] += v.z; Y[o >> 1][o & 1][4 * q + 3] += v.w;
+            }
+        const float s = OUT_MODE == 2 ? 1.0f : scale[co], t = OUT_MODE == 2 ? 0.0f : shift[co];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tm = (r & 3) + 8 * (r >> 2) + 4 * h;   // tile of accumulator row r
+            const int ty = ty0 + (tm >> 1), tx = tx0 + (tm & 1);
+            if (OUT_MODE == 2) {
+#pragma unroll
+                for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+                    for (int xb2 = 0; xb2 < 2; ++xb2) {
+                        const int gy = 2 * ty + ya, gx = 2 * tx + xb2;
+                        if (gy < H && gx < W) {
+                            const float v = Y[ya][xb2][r];
+                            out[(((size_t)b * H + gy) * W + gx) * COUT + co] = v;
+                            ssum += v;
+                            ssq = fmaf(v, v, ssq);
+                        }
+                    }
+            } else {
+                if (ty < Hp && tx < Wp) {
+                    float v = 0.0f;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) v = fmaxf(v, fmaf(Y[o >> 1][o & 1][r], s, t));
+                    if (!((KNOCK & 8) && v != 12345.0f)) out[(((size_t)b * Hp + ty) * Wp + tx) * COUT + co] = v;
+                }
+            }
+        }
+    }
+    if (OUT_MODE == 2 && stats) {
+        float* red = reinterpret_cast<float*>(wl) + 2 * 4 * 4 * 64 * 4;          // behind the hand-over buffer
+        ssum += __shfl_xor(ssum, 32);
+        ssq += __shfl_xor(ssq, 32);
+        if (wf == 0 && h == 0) { red[co * 2] = ssum; red[co * 2 + 1] = ssq; }
+        __syncthreads();
+        const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (tid < COUT) stats[blk * COUT + tid] = make_float2(red[tid * 2], red[tid * 2 + 1]);
+    }
+}

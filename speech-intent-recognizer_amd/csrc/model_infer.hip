@@ -1,6 +1,7 @@
 // sir_model_infer: eval-mode CNNAudioGRU.forward + argmax (models/models.py:41-68, scripts/evaluate.py:82-83)
 // as a fixed sequence of hand-written kernels on one stream.  See model_kernels.h for the kernels.
 #include "bf16x6_kernels.h"
+#include "conv_wino_bf16x6_kernel.h"
 
 namespace {
 
@@ -49,7 +50,7 @@ void ws_sizes(const Dims& d, size_t* bytes) {
     bytes[WS_WHT] = (size_t)4 * 768 * 256 * 6;                  // W_hh as the resident bf16x3 MFMA fragments of the recurrence kernel
     bytes[WS_XS] = B * d.S * 1024 * 3 * 2;
     bytes[WS_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512) * 2;
-    bytes[WS_WCB] = ((size_t)3 * 32 * 9 * 64 + (size_t)3 * 64 * 9 * 128) * 2;
+    bytes[WS_WCB] = ((size_t)3 * 32 * 16 * 64 + (size_t)3 * 64 * 9 * 128) * 2;     // conv2: 16 Winograd frequencies per (cout, cin); conv3: 9 taps
     bytes[WS_GXB] = sir_gru_xbuf_bytes(d.B);
     bytes[WS_GFL] = 0;
 }
@@ -118,7 +119,7 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     unsigned short* wsl0 = (unsigned short*)(ws + off[WS_WS]);
     unsigned short* wsl1 = wsl0 + (size_t)2 * 3 * 768 * 1024;
     unsigned short* wcb2 = (unsigned short*)(ws + off[WS_WCB]);
-    unsigned short* wcb3 = wcb2 + (size_t)3 * 32 * 9 * 64;
+    unsigned short* wcb3 = wcb2 + (size_t)3 * 32 * 16 * 64;
     float* gxb = (float*)(ws + off[WS_GXB]);
     const int B = d.B, S = d.S;
 
@@ -137,7 +138,7 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
             hipLaunchKernelGGL(prep_bn_kernel, dim3(1), dim3(128), 0, st, w->bn_w[i], w->bn_b[i], w->bn_mean[i], w->bn_var[i],
                                bns + bn_o[i], bnt + bn_o[i], bn_c[i]);
         for (int i = 0; i < 4; ++i) sir_prep_whh_quad(st, w->gru_w_hh[i], (unsigned char*)wht + (size_t)i * 768 * 256 * 6);
-        hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((32 * 9 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], wcb2, 32, 64);
+        hipLaunchKernelGGL(prep_conv_w_wino_bf16x3_kernel, dim3((32 * 16 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], wcb2, 32, 64);
         hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], wcb3, 64, 128);
         for (int dir = 0; dir < 2; ++dir) {
             hipLaunchKernelGGL(split3_kernel, dim3(384), dim3(256), 0, st, w->gru_w_ih[dir], 1024, wsl0 + (size_t)dir * 3 * 768 * 1024, (size_t)768, 1024);
@@ -156,7 +157,8 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     }
     {
         SirProfScope prof(h, SIR_K_CONV2, st);
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 0, 0, 3, 0>), dim3((d.wp1 + 7) / 8, 1, B), dim3(256), conv_ns_lds_bytes(4, 2), st,
+        // conv2 as Winograd F(2x2, 3x3): the 2x2 output tile is the pooling window (conv_wino_bf16x6_kernel.h)
+        hipLaunchKernelGGL((conv3x3_wino_bf16x6_kernel<32, 64, 0>), dim3(((d.wp1 + 1) / 2 + 1) / 2, 1, B), dim3(256), WINO_LDS_BYTES, st,
                            a1, (const unsigned short*)wcb2, bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
     }
     {

@@ -42,6 +42,7 @@ struct TDims {
     int B, T, wp1, wp2, wp3, S;
     int c1gx, c1gy;          // conv1 grids (ceil over un-pooled odd columns)
     int c2gx, c3gx, c3fx;      // c3fx: conv3 FORWARD grid (16x8-pixel tiles); c3gx: conv3 data-gradient grid (16x16)
+    int c2wx;                  // conv2 FORWARD grid: Winograd blocks of two tile columns (4 pixels)
     int wg2_blocks, wg3_blocks, wg2_rb, wg3_rb;
     int ksplits, kchunk;
 };
@@ -53,6 +54,7 @@ bool make_tdims(int batch, int t, TDims* d) {
     d->c1gx = ((t + 1) / 2 + C1_PCOLS - 1) / C1_PCOLS;
     d->c1gy = (32 + C1_PROWS - 1) / C1_PROWS;
     d->c2gx = (d->wp1 + 7) / 8;
+    d->c2wx = ((d->wp1 + 1) / 2 + 1) / 2;
     d->c3gx = (d->wp2 + 15) / 16;
     d->c3fx = (d->wp2 + 7) / 8;
     d->wg2_rb = 32; d->wg3_rb = 16;                    // rows per workgroup of the weight-gradient kernels: one image each (256 workgroups at batch 256)
@@ -81,7 +83,7 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     n[TB_BN] = 4 * 224;
     n[TB_BNB] = 2 * 224;
     size_t st = (size_t)d.c1gx * d.c1gy * B * 32;                       // conv1 partials (float2)
-    const size_t s2 = (size_t)d.c2gx * B * 64, s3 = (size_t)d.c3fx * B * 128;
+    const size_t s2 = (size_t)d.c2wx * B * 64, s3 = (size_t)d.c3fx * B * 128;
     if (s2 > st) st = s2;
     if (s3 > st) st = s3;
     const size_t bw = (size_t)(B * 16 * d.wp1 / 64 + 64) * 128;          // bn backward partials, generous
@@ -111,7 +113,7 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     n[TB_SLAB] = slab + (size_t)WGR_PARTS * 9 * 128 * 64;       // + the partial sums of the two-pass wgrad reduce
     n[TB_XS] = (B * S * 1024 * 3 + 1) / 2;                       // ushort count / 2 (sizes are in floats)
     n[TB_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512 + 1) / 2;
-    n[TB_WCB] = ((size_t)2 * (3 * 32 * 9 * 64 + 3 * 64 * 9 * 128) + 1) / 2;
+    n[TB_WCB] = ((size_t)(3 * 32 * 16 * 64 + 3 * 32 * 9 * 64) + (size_t)2 * 3 * 64 * 9 * 128 + 1) / 2;   // conv2 forward in Winograd form (16 frequencies)
     n[TB_GXB] = sir_gru_xbuf_bytes(d.B) / 4;
     n[TB_GFL] = 64;
     n[TB_C1M] = 2 * C1_NMOM;
@@ -156,7 +158,7 @@ TPtrs carve(void* ws, const size_t* off) {
     p.small = (float*)(b + off[TB_SMALL]); p.slab = (float*)(b + off[TB_SLAB]);
     p.xs = (unsigned short*)(b + off[TB_XS]);
     p.wsl0 = (unsigned short*)(b + off[TB_WS]); p.wsl1 = p.wsl0 + (size_t)2 * 3 * 768 * 1024;
-    p.wcb2 = (unsigned short*)(b + off[TB_WCB]); p.wcb3 = p.wcb2 + (size_t)3 * 32 * 9 * 64;
+    p.wcb2 = (unsigned short*)(b + off[TB_WCB]); p.wcb3 = p.wcb2 + (size_t)3 * 32 * 16 * 64;
     p.wcb2t = p.wcb3 + (size_t)3 * 64 * 9 * 128; p.wcb3t = p.wcb2t + (size_t)3 * 32 * 9 * 64;
     p.gxb = (float*)(b + off[TB_GXB]); p.gfl = (unsigned int*)(b + off[TB_GFL]);
     p.c1m = (double*)(b + off[TB_C1M]);
@@ -222,7 +224,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
             pj.kind[nj] = kind; pj.src[nj] = src; pj.dst[nj] = dst; pj.a[nj] = a; pj.b[nj] = b; pj.block0[nj] = blocks;
             blocks += nblk; ++nj;
         };
-        add(1, w->conv_w[1], p.wcb2, 32, 64, (32 * 9 * 64 + 255) / 256);
+        add(4, w->conv_w[1], p.wcb2, 32, 64, (32 * 16 * 64 + 255) / 256);       // conv2 forward: Winograd frequencies
         add(1, w->conv_w[2], p.wcb3, 64, 128, (64 * 9 * 128 + 255) / 256);
         add(2, w->conv_w[1], p.wcb2t, 32, 64, (32 * 9 * 64 + 255) / 256);
         add(2, w->conv_w[2], p.wcb3t, 64, 128, (64 * 9 * 128 + 255) / 256);
@@ -256,11 +258,11 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     // conv2 block: raw conv + partial statistics on MFMA, finalize, BN+ReLU+pool
     {
         { SirProfScope prof(h, SIR_K_T_CONV2, st);
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<32, 64, 4, 2, 2, 0, 3, 0>), dim3(d.c2gx, 1, B), dim3(256), conv_ns_lds_bytes(4, 2), st, (const float*)p.a1,
+        hipLaunchKernelGGL((conv3x3_wino_bf16x6_kernel<32, 64, 2>), dim3(d.c2wx, 1, B), dim3(256), WINO_LDS_BYTES, st, (const float*)p.a1,
                            (const unsigned short*)p.wcb2, (const float*)nullptr, (const float*)nullptr, p.z2, 32, d.wp1, 16, d.wp2, p.stats);
         }
         SirProfScope prof(h, SIR_K_T_BN2, st);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, d.c2gx * B, 64,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, d.c2wx * B, 64,
                            (double)B * 32 * d.wp1, w->bn_w[1], w->bn_b[1], bn_running_mean[1], bn_running_var[1], bn_momentum,
                            scale + 32, shift + 32, smean + 32, sinv + 32);
         hipLaunchKernelGGL(bn_relu_pool_kernel<false>, dim3(grid_for((size_t)B * 16 * d.wp2 * 16)), dim3(256), 0, st, p.z2,

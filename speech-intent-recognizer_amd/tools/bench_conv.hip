@@ -11,6 +11,7 @@
 #include <vector>
 #include "../csrc/bf16x6_kernels.h"
 #include "../tools/legacy_kernels.h"
+#include "../csrc/conv_wino_bf16x6_kernel.h"
 
 #define CK_(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -118,6 +119,109 @@ static void run(const char* name, int B, int H, int W) {
     hipFree(dx); hipFree(dw); hipFree(ds); hipFree(dt); hipFree(o1); hipFree(o2); hipFree(wpb);
 }
 
+// Winograd F(2x2, 3x3) conv2 against the direct kernel: same input, same weights, pooled BN + ReLU output and raw output
+static void run_wino(int B, int H, int W) {
+    constexpr int CIN = 32, COUT = 64;
+    const int Hp = H / 2, Wp = W / 2, reps = 60;
+    const size_t nx = (size_t)B * H * W * CIN, nw = (size_t)COUT * CIN * 9, npool = (size_t)B * Hp * Wp * COUT, nraw = (size_t)B * H * W * COUT;
+    std::vector<float> hx(nx), hw(nw), hs(COUT), ht(COUT);
+    srand(11);
+    for (auto& v : hx) v = rand() / (float)RAND_MAX * 2.0f - 0.3f;
+    for (auto& v : hw) v = (rand() / (float)RAND_MAX - 0.5f) * 0.2f;
+    for (int c = 0; c < COUT; ++c) { hs[c] = 0.5f + rand() / (float)RAND_MAX; ht[c] = rand() / (float)RAND_MAX - 0.5f; }
+    float *dx, *dw, *ds, *dt, *o1, *o2;
+    unsigned short *wpb, *wpw;
+    float2 *st1, *st2;
+    CK_(hipMalloc(&dx, nx * 4)); CK_(hipMalloc(&dw, nw * 4)); CK_(hipMalloc(&ds, COUT * 4)); CK_(hipMalloc(&dt, COUT * 4));
+    CK_(hipMalloc(&o1, nraw * 4)); CK_(hipMalloc(&o2, nraw * 4)); CK_(hipMalloc(&wpb, nw * 6)); CK_(hipMalloc(&wpw, (size_t)COUT * CIN * 16 * 6));
+    const dim3 gd((W + 7) / 8, (H + 31) / 32, B), gw(((W + 1) / 2 + 1) / 2, (H + 31) / 32, B);
+    CK_(hipMalloc(&st1, (size_t)gd.x * gd.y * B * COUT * 8)); CK_(hipMalloc(&st2, (size_t)gw.x * gw.y * B * COUT * 8));
+    CK_(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
+    CK_(hipMemcpy(ds, hs.data(), COUT * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(dt, ht.data(), COUT * 4, hipMemcpyHostToDevice));
+    hipStream_t st; CK_(hipStreamCreate(&st));
+    hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((CIN * 9 * COUT + 255) / 256), dim3(256), 0, st, (const float*)dw, wpb, CIN, COUT);
+    hipLaunchKernelGGL(prep_conv_w_wino_bf16x3_kernel, dim3((CIN * 16 * COUT + 255) / 256), dim3(256), 0, st, (const float*)dw, wpw, CIN, COUT);
+    printf("conv2 as Winograd F(2x2,3x3): B=%d %dx%d %d->%d  grid %dx%dx%d (direct: %dx%dx%d)\n", B, H, W, CIN, COUT, gw.x, gw.y, gw.z, gd.x, gd.y, gd.z);
+    auto compare = [&](const char* what, size_t n, bool is_stats) {
+        std::vector<float> h1(n), h2(n);
+        CK_(hipStreamSynchronize(st));
+        CK_(hipMemcpy(h1.data(), o1, n * 4, hipMemcpyDeviceToHost)); CK_(hipMemcpy(h2.data(), o2, n * 4, hipMemcpyDeviceToHost));
+        double d = 0, mx = 0, sq = 0;
+        for (size_t i = 0; i < n; ++i) { d = fmax(d, fabs((double)h1[i] - h2[i])); mx = fmax(mx, fabs(h1[i])); sq += (double)h1[i] * h1[i]; }
+        printf("  %-28s max |direct - winograd| = %.3e  (max |out| %.3f, rms %.3f)\n", what, d, mx, sqrt(sq / n));
+        (void)is_stats;
+    };
+    // pooled BN + ReLU output
+    CK_(hipMemsetAsync(o1, 0, nraw * 4, st)); CK_(hipMemsetAsync(o2, 0, nraw * 4, st));
+    const float t1 = time_us(st, reps, [&] {
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, 4, 2, 0, 0, 3, 0>), gd, dim3(256), conv_ns_lds_bytes(4, 2), st, (const float*)dx, (const unsigned short*)wpb,
+                           (const float*)ds, (const float*)dt, o1, H, W, Hp, Wp, (float2*)nullptr); });
+    const float t2 = time_us(st, reps, [&] {
+        hipLaunchKernelGGL((conv3x3_wino_bf16x6_kernel<CIN, COUT, 0, 2>), gw, dim3(256), WINO_LDS_BYTES, st, (const float*)dx, (const unsigned short*)wpw,
+                           (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
+    const double gf = 2.0 * B * H * W * (double)COUT * CIN * 9 * 1e-9;
+    const float t2b = time_us(st, reps, [&] {
+        hipLaunchKernelGGL((conv3x3_wino_bf16x6_kernel<CIN, COUT, 0, 3>), gw, dim3(256), WINO_LDS_BYTES, st, (const float*)dx, (const unsigned short*)wpw,
+                           (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
+    if (B >= 64) {
+        // the same launches over FOUR rotating inputs (4 x 105 MB: more than the 256 MB MALL holds), as inside the model where every
+        // launch reads activations the previous kernel just wrote: the timings above re-read one input that stays cached
+        float* dxr[4];
+        for (int k = 0; k < 4; ++k) { CK_(hipMalloc(&dxr[k], nx * 4)); CK_(hipMemcpyAsync(dxr[k], dx, nx * 4, hipMemcpyDeviceToDevice, st)); }
+        int rot = 0;
+        const float r1 = time_us(st, reps, [&] {
+            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, 4, 2, 0, 0, 3, 0>), gd, dim3(256), conv_ns_lds_bytes(4, 2), st, (const float*)dxr[rot++ & 3], (const unsigned short*)wpb,
+                               (const float*)ds, (const float*)dt, o1, H, W, Hp, Wp, (float2*)nullptr); });
+        const float r2 = time_us(st, reps, [&] {
+            hipLaunchKernelGGL((conv3x3_wino_bf16x6_kernel<CIN, COUT, 0, 3, 0>), gw, dim3(256), WINO_LDS_BYTES, st, (const float*)dxr[rot++ & 3], (const unsigned short*)wpw,
+                               (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
+        const float r3 = time_us(st, reps, [&] {
+            hipLaunchKernelGGL((conv3x3_wino_bf16x6_kernel<CIN, COUT, 0, 3, 1>), gw, dim3(256), WINO_LDS_BYTES, st, (const float*)dxr[rot++ & 3], (const unsigned short*)wpw,
+                               (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
+        const float r4 = time_us(st, reps, [&] {
+            hipLaunchKernelGGL((conv3x3_wino_bf16x6_kernel<CIN, COUT, 0, 2, 1>), gw, dim3(256), WINO_LDS_BYTES, st, (const float*)dxr[rot++ & 3], (const unsigned short*)wpw,
+                               (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
+        printf("  rotating inputs:   direct %.1f us   winograd %.1f us, with the XCD-aware block order %.1f us (2 workgroups/CU: %.1f us)\n", r1, r2, r3, r4);
+        auto ko = [&](auto kc) {
+            return time_us(st, reps, [&] {
+                hipLaunchKernelGGL((conv3x3_wino_bf16x6_kernel<CIN, COUT, 0, 3, 1, decltype(kc)::value>), gw, dim3(256), WINO_LDS_BYTES, st, (const float*)dxr[rot++ & 3],
+                                   (const unsigned short*)wpw, (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, (float2*)nullptr); });
+        };
+        using std::integral_constant;
+        printf("  winograd knock-outs (timing only): no loads %.1f, no transform/split/LDS writes %.1f, no MFMAs %.1f, no stores %.1f, loads+transform %.1f, all but MFMA %.1f, all %.1f us\n",
+               ko(integral_constant<int, 1>{}), ko(integral_constant<int, 2>{}), ko(integral_constant<int, 4>{}), ko(integral_constant<int, 8>{}),
+               ko(integral_constant<int, 3>{}), ko(integral_constant<int, 11>{}), ko(integral_constant<int, 15>{}));
+        for (int k = 0; k < 4; ++k) (void)hipFree(dxr[k]);
+    }
+    printf("  BN + ReLU + pool:  direct %.1f us (%.1f TF)   winograd %.1f us (%.1f TF algorithmic); at 3 workgroups/CU: %.1f us\n", t1, gf * 1e3 / t1, t2, gf * 1e3 / t2, t2b);
+    compare("pooled output", npool, false);
+    // raw output + statistics
+    CK_(hipMemsetAsync(o1, 0, nraw * 4, st)); CK_(hipMemsetAsync(o2, 0, nraw * 4, st));
+    const float t3 = time_us(st, reps, [&] {
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, 4, 2, 2, 0, 3, 0>), gd, dim3(256), conv_ns_lds_bytes(4, 2), st, (const float*)dx, (const unsigned short*)wpb,
+                           (const float*)nullptr, (const float*)nullptr, o1, H, W, Hp, Wp, st1); });
+    const float t4 = time_us(st, reps, [&] {
+        hipLaunchKernelGGL((conv3x3_wino_bf16x6_kernel<CIN, COUT, 2>), gw, dim3(256), WINO_LDS_BYTES, st, (const float*)dx, (const unsigned short*)wpw,
+                           (const float*)nullptr, (const float*)nullptr, o2, H, W, Hp, Wp, st2); });
+    printf("  raw + statistics:  direct %.1f us   winograd %.1f us\n", t3, t4);
+    compare("raw output", nraw, false);
+    {   // channel statistics: totals over the workgroups
+        const size_t n1 = (size_t)gd.x * gd.y * B, n2 = (size_t)gw.x * gw.y * B;
+        std::vector<float2> s1(n1 * COUT), s2(n2 * COUT);
+        CK_(hipMemcpy(s1.data(), st1, s1.size() * 8, hipMemcpyDeviceToHost)); CK_(hipMemcpy(s2.data(), st2, s2.size() * 8, hipMemcpyDeviceToHost));
+        double worst = 0;
+        for (int c = 0; c < COUT; ++c) {
+            double a = 0, aq = 0, bsum = 0, bq = 0;
+            for (size_t k = 0; k < n1; ++k) { a += s1[k * COUT + c].x; aq += s1[k * COUT + c].y; }
+            for (size_t k = 0; k < n2; ++k) { bsum += s2[k * COUT + c].x; bq += s2[k * COUT + c].y; }
+            worst = fmax(worst, fmax(fabs(a - bsum) / (fabs(a) + 1.0), fabs(aq - bq) / (fabs(aq) + 1.0)));
+        }
+        printf("  channel statistics: worst relative difference of (sum, sum of squares) = %.3e\n", worst);
+    }
+    (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(ds); (void)hipFree(dt); (void)hipFree(o1); (void)hipFree(o2); (void)hipFree(wpb); (void)hipFree(wpw);
+    (void)hipFree(st1); (void)hipFree(st2);
+}
+
 // `bench_conv loop [seconds]`: the product conv2 launch back to back, for sampling clocks and power from outside
 // (rocm-smi --showclocks --showpower in a second shell) -- is the kernel running at the power cap?
 static void load_loop(double seconds) {
@@ -153,6 +257,7 @@ static void load_loop(double seconds) {
 
 int main(int argc, char** argv) {
     if (argc > 1 && std::string(argv[1]) == "loop") { load_loop(argc > 2 ? atof(argv[2]) : 3.0); return 0; }
+    if (argc > 1 && std::string(argv[1]) == "wino") { run_wino(256, 32, 100); run_wino(3, 32, 47); return 0; }
     run<64, 128, 2, 4, 1>("conv3", 256, 16, 50);
     run<64, 128, 2, 2, 1>("conv3, 16x8-pixel tile (4 patches per wave)", 256, 16, 50);
     run<32, 64, 4, 2, 0>("conv2", 256, 32, 100);
