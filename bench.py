@@ -72,6 +72,7 @@ FLOPS_PER_UTT = {
     "bwd_conv3_wgrad": _CONV3, "bwd_conv3_dgrad": _CONV3, "bwd_conv2_wgrad": _CONV2, "bwd_conv2_dgrad": _CONV2,
 }
 BF16X6_KERNELS = {k for k in FLOPS_PER_UTT if "conv1" not in k}
+WINOGRAD_KERNELS = {"conv2_mfma_bn_relu_pool", "train_conv2_fwd"}     # csrc/conv_wino_bf16x6_kernel.h
 FWD_FLOPS_PER_UTT = 400646144
 TRAIN_FLOPS_PER_UTT = 3 * FWD_FLOPS_PER_UTT                  # fwd + dgrad + wgrad convention: 1 201 938 432
 FEATURE_BYTES_PER_UTT = CLIP_LEN * 4 + 64 * T_PAD * 4       # 243 200 B (fp32 waveform in, features out)
@@ -283,12 +284,16 @@ def mfma_roofline(kernel, avg_ms, launches, batch=BATCH):
     x6 = kernel in BF16X6_KERNELS
     peak = PEAK_BF16X6_TFLOPS if x6 else PEAK_F32_MFMA_TFLOPS
     traffic, source = pmc_traffic(kernel)
-    return {"kernel": kernel, "bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": source,
-            "avg_launch_ms": round(avg_ms, 5), "launches": launches, "flops_per_launch": flops,
-            "mfma_path": ("bf16x6: fp32 product = 6 bf16 MFMA products, f32 accumulate; peak = 2500/6 "
-                          "algorithmic TFLOP/s; executed bf16 MFMA rate = 6 x achieved") if x6 else "v_mfma_f32_32x32x2_f32",
-            "fp32_mfma_peak": PEAK_F32_MFMA_TFLOPS}
+    out = {"kernel": kernel, "bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+           "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": source,
+           "avg_launch_ms": round(avg_ms, 5), "launches": launches, "flops_per_launch": flops,
+           "mfma_path": ("bf16x6: fp32 product = 6 bf16 MFMA products, f32 accumulate; peak = 2500/6 "
+                         "algorithmic TFLOP/s; executed bf16 MFMA rate = 6 x achieved") if x6 else "v_mfma_f32_32x32x2_f32",
+           "fp32_mfma_peak": PEAK_F32_MFMA_TFLOPS}
+    if kernel in WINOGRAD_KERNELS:
+        out["algorithm"] = ("Winograd F(2x2,3x3): flops_per_launch counts the DIRECT convolution (the algorithmic work); the "
+                            "kernel executes 16/36 of its products, i.e. executed bf16 MFMA rate = 6 x 16/36 x achieved")
+    return out
 
 
 def main():

@@ -19,7 +19,7 @@ import sys
 NAME_MAP = [
     ("feat_utt_kernel", "feat_frames"), ("feat_frames_kernel", "feat_frames"), ("feat_normalise_kernel", "feat_normalise"),
     ("conv1_mfma_bn_relu_pool_kernel", "conv1_bn_relu_pool"), ("conv1_bn_relu_pool_kernel", "conv1_bn_relu_pool"),
-    ("conv3x3_bf16x6_ns_kernel<32, 64", "conv2_mfma_bn_relu_pool"), ("conv3x3_bf16x6_ns_kernel<64, 128", "conv3_mfma_bn_relu_pool"),
+    ("conv3x3_wino_bf16x6_kernel<32, 64", "conv2_mfma_bn_relu_pool"), ("conv3x3_bf16x6_ns_kernel<32, 64", "conv2_mfma_bn_relu_pool"), ("conv3x3_bf16x6_ns_kernel<64, 128", "conv3_mfma_bn_relu_pool"),
     ("gemm_nt_bf16x6_v3_kernel", "gemm_ih"),
     ("conv3x3_bf16x6_kernel<32, 64", "conv2_mfma_bn_relu_pool"), ("conv3x3_bf16x6_kernel<64, 128", "conv3_mfma_bn_relu_pool"),
     ("conv3x3_mfma_kernel<32, 64", "conv2_mfma_bn_relu_pool"), ("conv3x3_mfma_kernel<64, 128", "conv3_mfma_bn_relu_pool"),

@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_wino_bf16x6_kernel(
                     R[1][j] = make_float4(a0.x - a2.x, a0.y - a2.y, a0.z - a2.z, a0.w - a2.w);
                 }
             }
+            uint2 sh[2][4], sm_[2][4], sl[2][4];
 #pragma unroll
             for (int ii = 0; ii < ((KNOCK & 2) ? 0 : 2); ++ii) {
                 const float4 r0 = R[ii][0], r1 = R[ii][1], r2 = R[ii][2], r3 = R[ii][3];
@@ -160,15 +161,17 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_wino_bf16x6_kernel(
                                      make_float4(r2.x - r1.x, r2.y - r1.y, r2.z - r1.z, r2.w - r1.w),
                                      make_float4(r1.x - r3.x, r1.y - r3.y, r1.z - r3.z, r1.w - r3.w)};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint2 hh, mm, ll;
-                    split3_quad(V[j], hh, mm, ll);
-                    unsigned char* d = vdst + (4 * (2 * wf + ii) + j) * FB;
-                    *reinterpret_cast<uint2*>(d) = hh;
-                    *reinterpret_cast<uint2*>(d + PLB) = mm;
-                    *reinterpret_cast<uint2*>(d + 2 * PLB) = ll;
-                }
+                for (int j = 0; j < 4; ++j) split3_quad(V[j], sh[ii][j], sm_[ii][j], sl[ii][j]);
             }
+#pragma unroll
+            for (int ii = 0; ii < ((KNOCK & 2) ? 0 : 2); ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned char* d = vdst + (4 * (2 * wf + ii) + j) * FB;
+                    *reinterpret_cast<uint2*>(d) = sh[ii][j];
+                    *reinterpret_cast<uint2*>(d + PLB) = sm_[ii][j];
+                    *reinterpret_cast<uint2*>(d + 2 * PLB) = sl[ii][j];
+                }
         }
         __syncthreads();
         const unsigned char* afrag = wl + h * 512 + m * 16 + 8 * wf * FB;
@@ -270,3 +273,4 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_wino_bf16x6_kernel(
         if (tid < COUT) stats[blk * COUT + tid] = make_float2(red[tid * 2], red[tid * 2 + 1]);
     }
 }
+
