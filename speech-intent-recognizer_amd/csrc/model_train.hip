@@ -318,10 +318,14 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
 extern "C" int sir_ce_loss(sir_handle* h, const float* logits, const int64_t* labels, int batch, int num_classes,
                            float* loss, float* dlogits, float grad_scale, void* stream_) {
     if (!h || !logits || !labels || !loss) { sir_set_error("sir_ce_loss: NULL argument"); return SIR_EINVAL; }
-    if (batch < 1 || num_classes < 1) { sir_set_error("sir_ce_loss: bad shape"); return SIR_EINVAL; }
+    if (batch < 1 || num_classes < 1 || num_classes > 64) { sir_set_error("sir_ce_loss: bad shape batch=%d num_classes=%d (1..64)", batch, num_classes); return SIR_EINVAL; }
     SirProfScope prof(h, SIR_K_CE, (hipStream_t)stream_);
-    hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, logits, (const long long*)labels, batch,
-                       num_classes, loss, dlogits, grad_scale);
+    if (num_classes <= 32)
+        hipLaunchKernelGGL(ce_loss_kernel<32>, dim3(1), dim3(256), 0, (hipStream_t)stream_, logits, (const long long*)labels, batch,
+                           num_classes, loss, dlogits, grad_scale);
+    else
+        hipLaunchKernelGGL(ce_loss_kernel<64>, dim3(1), dim3(256), 0, (hipStream_t)stream_, logits, (const long long*)labels, batch,
+                           num_classes, loss, dlogits, grad_scale);
     KCHECK();
     return SIR_OK;
 }
@@ -361,9 +365,8 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
     if (part != SIR_BWD_CNN) {
     // ---- head: fc + attention pooling ----------------------------------------------------
     { SirProfScope prof(h, SIR_K_B_HEAD, st);
-    hipLaunchKernelGGL(fc_wgrad_kernel, dim3(C, 2), dim3(256), 0, st, dlogits, (const float*)p.ctx, g->fc_w, g->fc_b, B, C);
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, st, dlogits, w->fc_w, (const float*)p.y1, w->attn_w, w->attn_b,
-                       p.dy1, daw_part, dab_part, S, C);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(B + 2 * C), dim3(256), 0, st, dlogits, w->fc_w, (const float*)p.y1, w->attn_w, w->attn_b,
+                       (const float*)p.ctx, p.dy1, daw_part, dab_part, g->fc_w, g->fc_b, B, S, C);
     hipLaunchKernelGGL(head_colsum_kernel, dim3(9), dim3(256), 0, st, (const float*)daw_part, (const float*)dab_part, B, g->attn_w, g->attn_b); }
     KCHECK();
 

@@ -247,24 +247,34 @@ static __global__ __launch_bounds__(256) void dropout_split3_kernel(const float*
 // dlogits = (softmax - onehot) * grad_scale / B      (nn.CrossEntropyLoss(), train.py:242)
 // single workgroup, deterministic reduction
 // ------------------------------------------------------------------------------------------
+template <int CMAX>
 static __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
                                                        int B, int C, float* __restrict__ loss, float* __restrict__ dlogits,
                                                        float grad_scale) {
     __shared__ float red[256];
     float acc = 0.0f;
     for (int b = threadIdx.x; b < B; b += 256) {
+        // the row goes into registers with ALL its loads in flight (C <= CMAX, dispatched by the host): the per-class loops of
+        // the first version waited for one dependent load after the other, 15 us for 256 x 31 logits
         const float* r = logits + (size_t)b * C;
-        float mx = r[0];
-        for (int c = 1; c < C; ++c) mx = fmaxf(mx, r[c]);
-        float den = 0.0f;
-        for (int c = 0; c < C; ++c) den += expf(r[c] - mx);
         const int y = (int)labels[b];
+        float v[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) v[c] = c < C ? r[c] : 0.0f;
+        const float ry = r[y];
+        float mx = v[0];
+#pragma unroll
+        for (int c = 1; c < CMAX; ++c) if (c < C) mx = fmaxf(mx, v[c]);
+        float den = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = expf(v[c] - mx); den += v[c]; }
         const float lse = mx + logf(den);
-        acc += lse - r[y];
+        acc += lse - ry;
         if (dlogits) {
             const float inv = 1.0f / den, gs = grad_scale / (float)B;
-            for (int c = 0; c < C; ++c)
-                dlogits[(size_t)b * C + c] = (expf(r[c] - mx) * inv - (c == y ? 1.0f : 0.0f)) * gs;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (c < C) dlogits[(size_t)b * C + c] = (v[c] * inv - (c == y ? 1.0f : 0.0f)) * gs;
         }
     }
     red[threadIdx.x] = acc;
@@ -281,14 +291,14 @@ static __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __rest
 //   dy_t = w_t dctx + ds_t a;  per-utterance partials of d attention.weight / d attention.bias
 // one workgroup per utterance
 // ------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ fcw,
-                                                        const float* __restrict__ y, const float* __restrict__ aw,
-                                                        const float* __restrict__ ab, float* __restrict__ dy,
-                                                        float* __restrict__ daw_part, float* __restrict__ dab_part,
-                                                        int S, int C) {
+__device__ __forceinline__ void head_bwd_utt(int b, const float* __restrict__ dlogits, const float* __restrict__ fcw,
+                                             const float* __restrict__ y, const float* __restrict__ aw,
+                                             const float* __restrict__ ab, float* __restrict__ dy,
+                                             float* __restrict__ daw_part, float* __restrict__ dab_part,
+                                             int S, int C) {
     __shared__ float dctx[512];
     __shared__ float sc[ATT_MAX_S], ds[ATT_MAX_S];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* yb = y + (size_t)b * S * 512;
     for (int c = tid; c < 512; c += 256) {
         float a = 0.0f;
@@ -361,8 +371,10 @@ static __global__ __launch_bounds__(256) void colsum_kernel(const float* __restr
     __shared__ float red[4][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
     float a = 0.0f;
-    if (col < n_cols)
+    if (col < n_cols) {
+#pragma unroll 8
         for (int r = part; r < rows; r += 4) a += in[(size_t)r * ld + col];
+    }
     red[part][threadIdx.x & 63] = a;
     __syncthreads();
     if (part == 0 && col < n_cols) out[col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
@@ -376,7 +388,10 @@ static __global__ __launch_bounds__(256) void head_colsum_kernel(const float* __
     const bool bias = blockIdx.x == 8;
     const int l = threadIdx.x & 63, col = blockIdx.x * 64 + l, part = threadIdx.x >> 6;
     float a = 0.0f;
-    if (!bias) { for (int r = part; r < rows; r += 4) a += daw_part[(size_t)r * 512 + col]; }
+    if (!bias) {
+#pragma unroll 8
+        for (int r = part; r < rows; r += 4) a += daw_part[(size_t)r * 512 + col];     // 8 loads in flight, added in row order
+    }
     else { for (int r = threadIdx.x; r < rows; r += 256) a += dab_part[r]; }
     if (bias) {                                   // 256 partial sums -> one value, fixed order
 #pragma unroll
@@ -418,8 +433,10 @@ static __global__ __launch_bounds__(256) void colsum_partial_kernel(const float*
     const int per = (rows + gridDim.y - 1) / gridDim.y;
     const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
     float a = 0.0f;
-    if (col < n_cols)
+    if (col < n_cols) {
+#pragma unroll 8
         for (int r = r0 + part; r < r1; r += 4) a += in[(size_t)r * ld + col];
+    }
     red[part][threadIdx.x & 63] = a;
     __syncthreads();
     if (part == 0 && col < n_cols)
@@ -429,10 +446,10 @@ static __global__ __launch_bounds__(256) void colsum_partial_kernel(const float*
 // dfc_w[j][c] = sum_b dlogits[b][j] ctx[b][c];  dfc_b[j] = sum_b dlogits[b][j]
 //   grid (C, 2): block (j, half) owns 256 columns c; the dlogits column is staged in LDS once and the loop over
 //   the batch is unrolled so that the ctx loads pipeline (the first version ran one dependent load per iteration)
-static __global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __restrict__ dlogits, const float* __restrict__ ctx,
-                                                        float* __restrict__ dw, float* __restrict__ db, int B, int C) {
+__device__ __forceinline__ void fc_wgrad_block(int j, int half, const float* __restrict__ dlogits, const float* __restrict__ ctx,
+                                               float* __restrict__ dw, float* __restrict__ db, int B, int C) {
     __shared__ float dl[1024];
-    const int j = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    const int c = half * 256 + threadIdx.x;
     float a = 0.0f, sb = 0.0f;
     for (int b0 = 0; b0 < B; b0 += 1024) {
         const int nb = min(1024, B - b0);
@@ -451,6 +468,23 @@ static __global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __res
     }
     dw[(size_t)j * 512 + c] = a;
     if (c == 0) db[j] = sb;
+}
+
+// head backward, ONE launch for two independent jobs (both only need dlogits): workgroups [0, B) = one utterance each
+// (head_bwd_utt: fc + attention pooling backward, per-utterance attention partials); workgroups [B, B + 2 C) = the fc weight /
+// bias gradients (fc_wgrad_block).  head_colsum_kernel adds the attention partials afterwards.
+static __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ fcw,
+                                                              const float* __restrict__ y, const float* __restrict__ aw,
+                                                              const float* __restrict__ ab, const float* __restrict__ ctx,
+                                                              float* __restrict__ dy, float* __restrict__ daw_part,
+                                                              float* __restrict__ dab_part, float* __restrict__ d_fc_w,
+                                                              float* __restrict__ d_fc_b, int B, int S, int C) {
+    if ((int)blockIdx.x >= B) {
+        const int i = blockIdx.x - B;
+        fc_wgrad_block(i >> 1, i & 1, dlogits, ctx, d_fc_w, d_fc_b, B, C);
+        return;
+    }
+    head_bwd_utt(blockIdx.x, dlogits, fcw, y, aw, ab, dy, daw_part, dab_part, S, C);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -895,6 +929,7 @@ static __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int n
     if (idx >= total) return;
     const int ci = idx % cin, co = (idx / cin) % cout, tap = idx / (cin * cout);
     float s = 0.0f;
+#pragma unroll 8
     for (int k = 0; k < nparts; ++k) s += part[(size_t)k * total + idx];
     dw[((size_t)co * cin + ci) * 9 + tap] = s;
 }
