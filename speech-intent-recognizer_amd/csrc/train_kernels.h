@@ -86,6 +86,7 @@ static __global__ __launch_bounds__(256) void conv1_moments_reduce_kernel(const 
     __shared__ double rs[256];
     const int i = blockIdx.x, tid = threadIdx.x;
     double s = 0.0;
+#pragma unroll 8
     for (int r = tid; r < nblk; r += 256) s += part[(size_t)r * C1_NMOM + i];
     rs[tid] = s;
     __syncthreads();
@@ -146,6 +147,7 @@ static __global__ __launch_bounds__(256) void bn_finalize_kernel(const float2* _
     __shared__ double rs[256], rq[256];
     const int c = blockIdx.x, tid = threadIdx.x;
     double s = 0.0, q = 0.0;
+#pragma unroll 4
     for (int i = tid; i < nblk; i += 256) {
         const float2 v = stats[(size_t)i * C + c];
         s += v.x;
@@ -537,6 +539,7 @@ static __global__ void slab_reduce_jobs_kernel(SlabJobs jobs, int nslab) {
     float* __restrict__ o = jobs.out[j];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float a = 0.0f;
+#pragma unroll 8
         for (int z = 0; z < nslab; ++z) a += s[(size_t)z * n + i];
         o[i] = a;
     }
@@ -704,6 +707,7 @@ static __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float
     __shared__ double rs[256], rq[256];
     const int c = blockIdx.x, tid = threadIdx.x;
     double s = 0.0, q = 0.0;
+#pragma unroll 4
     for (int i = tid; i < nblk; i += 256) { const float2 v = part[(size_t)i * C + c]; s += v.x; q += v.y; }
     rs[tid] = s; rq[tid] = q;
     __syncthreads();
