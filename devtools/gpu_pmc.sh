@@ -9,4 +9,9 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY S
   timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmc/$tag -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train --streams 1 --repeats 1 > $R/gpurun_out/pmc/$tag.log 2>&1 || { echo "pmc group failed: $grp"; tail -5 $R/gpurun_out/pmc/$tag.log; }
   echo "done $grp"
 done
+# HBM traffic of the training-only kernels (three steps)
+for grp in "FETCH_SIZE" "WRITE_SIZE"; do
+  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmc/train_$grp -o pmc -- python3 $R/bench.py --steps 1 --warmup 1 --repeats 1 --train-steps 3 --no-cpu-baseline --no-augment --no-host-feed --streams 1 > $R/gpurun_out/pmc/train_$grp.log 2>&1 || { echo "pmc training pass failed: $grp"; tail -5 $R/gpurun_out/pmc/train_$grp.log; }
+  echo "done training $grp"
+done
 ls -R $R/gpurun_out/pmc | head -40

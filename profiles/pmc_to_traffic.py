@@ -17,6 +17,13 @@ import os
 import sys
 
 NAME_MAP = [
+    # training-only instantiations first (substring match, first hit wins)
+    ("conv3x3_wino_bf16x6_kernel<32, 64, 2", "train_conv2_fwd"), ("conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 2", "train_conv3_fwd"),
+    ("conv3x3_bf16x6_ns_kernel<64, 32", "bwd_conv2_dgrad"), ("conv3x3_bf16x6_ns_kernel<128, 64", "bwd_conv3_dgrad"),
+    ("conv_wgrad_bf16x6_kernel<32, 64>", "bwd_conv2_wgrad"), ("conv_wgrad_bf16x6_kernel<64, 128>", "bwd_conv3_wgrad"),
+    ("gru_quad_kernel<true>", "train_gru"), ("gru_bwd_pair_kernel", "bwd_gru"),
+    ("gemm_tn_bf16x6_kernel<true", "bwd_gru_dw"), ("gemm_tn_bf16x6_kernel<false", "bwd_gru_dx"),
+    ("bn_bwd_dz_kernel<false>", "bwd_bn2_dz"), ("bn_bwd_dz_kernel<true>", "bwd_bn3_dz"), ("conv1_bwd_kernel", "bwd_conv1"),
     ("feat_utt_kernel", "feat_frames"), ("feat_frames_kernel", "feat_frames"), ("feat_normalise_kernel", "feat_normalise"),
     ("conv1_mfma_bn_relu_pool_kernel", "conv1_bn_relu_pool"), ("conv1_bn_relu_pool_kernel", "conv1_bn_relu_pool"),
     ("conv3x3_wino_bf16x6_kernel<32, 64", "conv2_mfma_bn_relu_pool"), ("conv3x3_bf16x6_ns_kernel<32, 64", "conv2_mfma_bn_relu_pool"), ("conv3x3_bf16x6_ns_kernel<64, 128", "conv3_mfma_bn_relu_pool"),
@@ -41,6 +48,10 @@ def main(src, dst):
     out = {}
     if "gru_recurrence" in vals:                      # one kernel, two launches per step: bench.py reports them per layer
         vals["gru_recurrence_l0"] = vals["gru_recurrence_l1"] = vals["gru_recurrence"]
+    for both, names in (("train_gru", ("train_gru_l0", "train_gru_l1")), ("bwd_gru", ("bwd_gru_l0", "bwd_gru_l1"))):
+        if both in vals:                              # averages over the two layers' launches
+            for n in names:
+                vals[n] = vals[both]
     for name, cs in vals.items():
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             fetch = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024 * 2
