@@ -122,11 +122,36 @@ def pick_json_line(lines):
     return None
 
 
+def visible_gpu_count(kfd_nodes="/sys/class/kfd/kfd/topology/nodes", env=None):
+    """GPUs this process could use, counted WITHOUT touching HIP: KFD topology nodes with a non-zero simd_count, cut down
+    by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when one is set.  (torch.cuda.device_count()
+    falls back to hipGetDeviceCount when amdsmi is not importable, which initialises the runtime in the launcher parent.)
+    0 when there is no KFD topology at all (no amdgpu driver: no GPU); None when it exists but cannot be read: the caller
+    then skips the pre-check and lets the ranks fail."""
+    env = os.environ if env is None else env
+    if not os.path.isdir(kfd_nodes):
+        return 0
+    try:
+        n = 0
+        for node in sorted(os.listdir(kfd_nodes)):
+            with open(os.path.join(kfd_nodes, node, "properties")) as f:
+                for line in f:
+                    k, _, v = line.partition(" ")
+                    if k == "simd_count" and int(v) > 0:
+                        n += 1
+    except (OSError, ValueError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if env.get(var, "") != "":
+            n = min(n, len([x for x in env[var].split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(n_gpus, bench_args):
-    """Parent of an N-rank run.  No HIP call is made here: device_count() does not initialise the runtime."""
+    """Parent of an N-rank run.  No HIP call is made here (GPUs are counted from the KFD topology in sysfs)."""
     share = os.environ.get("SIR_BENCH_SHARE_GPU", "0") == "1"
-    ndev = torch.cuda.device_count()
-    if not share and ndev < n_gpus:
+    ndev = visible_gpu_count()
+    if not share and ndev is not None and ndev < n_gpus:
         print(f"bench.py: --gpus {n_gpus} but only {ndev} GPU(s) are visible (SIR_BENCH_SHARE_GPU=1 rehearses N ranks "
               "on one GPU over gloo)", file=sys.stderr)
         return 2
@@ -296,6 +321,60 @@ def mfma_roofline(kernel, avg_ms, launches, batch=BATCH):
     return out
 
 
+class GpuSensors:
+    """Package power (W) and shader clock (MHz) of one GPU read from the amdgpu hwmon files in sysfs (no HIP / SMI call, no
+    child process), sampled by a background thread while a region runs."""
+
+    def __init__(self, index=0, period=0.25):
+        import glob
+        self.period = period
+        self.power_file = self.sclk_file = None
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "power1_average")) or os.path.exists(os.path.join(c, "power1_input"))]
+        if index < len(cards):
+            for name in ("power1_average", "power1_input"):
+                f = os.path.join(cards[index], name)
+                if os.path.exists(f):
+                    self.power_file = f
+                    break
+            f = os.path.join(cards[index], "freq1_input")
+            self.sclk_file = f if os.path.exists(f) else None
+        self.samples = []
+        self._stop = None
+
+    @staticmethod
+    def _read(path, scale):
+        try:
+            with open(path) as f:
+                return int(f.read().strip()) * scale
+        except (OSError, ValueError):
+            return None
+
+    def __enter__(self):
+        import threading
+        self._stop = threading.Event()
+
+        def run():
+            while not self._stop.is_set():
+                self.samples.append((self._read(self.power_file, 1e-6) if self.power_file else None,
+                                     self._read(self.sclk_file, 1e-6) if self.sclk_file else None))
+                self._stop.wait(self.period)
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join()
+
+    def summary(self):
+        out = {"samples": len(self.samples), "source": "amdgpu hwmon (sysfs)" if self.power_file or self.sclk_file else None}
+        for i, key in enumerate(("power_W", "sclk_MHz")):
+            v = [s[i] for s in self.samples if s[i] is not None]
+            out[key] = {"mean": round(sum(v) / len(v), 1), "max": round(max(v), 1), "min": round(min(v), 1)} if v else None
+        return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -309,6 +388,11 @@ def main():
     ap.add_argument("--no-augment", dest="augment", action="store_false")
     ap.add_argument("--no-host-feed", action="store_true", help="skip the training leg fed from pinned host memory")
     ap.add_argument("--train-steps", type=int, default=20)
+    ap.add_argument("--sustain-seconds", type=float, default=6.0,
+                    help="one extra region of pipelined inference steps of at least this many seconds (0 = skip): long enough "
+                         "for a 5-second SMI sampler to see the load; reports throughput, package power and sclk")
+    ap.add_argument("--no-dist-leg", action="store_true",
+                    help="N = 1 only: skip the training leg that runs the RCCL gradient exchange in a one-rank nccl group")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("SIR_BENCH_STREAMS", "2")),
                     help="HIP streams the inference batches alternate over (each with its own buffers/workspace)")
     args = ap.parse_args()
@@ -468,6 +552,32 @@ def main():
                   "dominant_avg_launch_ms": round(iso_ms[dominant], 5), "dominant_launches": iso_cnt[dominant]}
     lib.sir_profile_enable(fz.handle, 0, -1)
 
+    # one long region of the SAME pipelined steps: >= --sustain-seconds of back-to-back batches so that
+    # an external SMI sampler sees the load, with package power / sclk sampled from sysfs beside it (the "matrix-core
+    # kernels sit at the power cap" claim of DESIGN.md section 4 then shows up in this line)
+    sustained = None
+    if args.sustain_seconds > 0:
+        chunk = 256
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        with GpuSensors(local_rank) as sens:
+            t0 = time.perf_counter()
+            n_done = 0
+            while True:
+                for i in range(chunk):
+                    step(n_done + i)
+                n_done += chunk
+                torch.cuda.synchronize()
+                if time.perf_counter() - t0 >= args.sustain_seconds:
+                    break
+            s_el = time.perf_counter() - t0
+        sustained = dict(value=round(batch * n_done / s_el, 1), unit="utterances/s (this rank)", steps=n_done,
+                         seconds=round(s_el, 3), ms_per_step=round(s_el / n_done * 1e3, 4),
+                         note=f"pipelined inference steps back to back, host sync every {chunk} steps", **sens.summary())
+        if rank == 0:
+            log(f"sustained region: {sustained['value']} utt/s over {s_el:.1f} s, sensors {sens.summary()}")
+
     # further legs (reported inside the same JSON line): the training step of BASELINE configs[2]/[3]/[4]
     # -- fused HIP features + forward/backward + Adam at per-GPU batch 256; with N > 1 each step
     # ends in the RCCL all-reduce (mean) of the flat 13 MB gradient buffer (two buckets, overlapped).
@@ -540,6 +650,31 @@ def main():
         train_info = train_leg(False)
         if args.augment:
             train_aug_info = train_leg(True)
+        if world == 1 and not args.no_dist_leg:
+            # the REAL collective backend on the one GPU of this box.  A one-rank "nccl" (RCCL) group, and the
+            # same training step taking the data-parallel path: async all-reduce of the GRU / head bucket on RCCL's stream beside
+            # the conv backward, the conv bucket, the waits and the 1/W scale.  The sum over one rank is the identity, so the
+            # difference to `train.value` is the per-step cost of the collective plumbing that every N pays once.
+            try:
+                import torch.distributed as dist1
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(free_port()))
+                dist1.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                train_ops.FORCE_EXCHANGE = True
+                try:
+                    leg = train_leg(False)
+                    backend = dist1.get_backend()
+                finally:
+                    train_ops.FORCE_EXCHANGE = False
+                    dist1.destroy_process_group()
+                train_info["rccl_world1"] = {
+                    "value": leg["value"], "unit": "utterances/s", "ms_per_step": leg["ms_per_step"], "backend": backend,
+                    "world_size": 1, "timed_regions": leg["timed_regions"],
+                    "vs_plain_step": round(leg["ms_per_step"] / train_info["ms_per_step"], 4),
+                    "path": "two-bucket overlapped gradient exchange (train_ops._exchange_and_scale) over a one-rank RCCL group"}
+            except Exception as e:                       # never lose the bench line to the extra leg
+                train_info["rccl_world1"] = {"error": f"{type(e).__name__}: {e}"}
+            log(f"train leg over a one-rank nccl group: {train_info['rccl_world1']}")
         if world == 1 and not args.no_host_feed:
             # the same training step fed from HOST memory -- pinned PCM16 batches (24.6 MB each, what a
             # loader would hand over), copied and featurised one batch ahead on a side stream (FeaturePrefetcher) -- so that
@@ -637,6 +772,8 @@ def main():
         }
         if single is not None:
             out["single_stream"] = single
+        if sustained is not None:
+            out["sustained"] = sustained
         if train_info is not None:
             out["train"] = train_info
         if train_aug_info is not None:

@@ -9,9 +9,9 @@
 #include <string>
 #include <type_traits>
 #include <vector>
-#include "../csrc/bf16x6_kernels.h"
-#include "../tools/legacy_kernels.h"
-#include "../csrc/conv_wino_bf16x6_kernel.h"
+#include "../../speech-intent-recognizer_amd/csrc/bf16x6_kernels.h"
+#include "legacy_kernels.h"
+#include "../../speech-intent-recognizer_amd/csrc/conv_wino_bf16x6_kernel.h"
 
 #define CK_(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 

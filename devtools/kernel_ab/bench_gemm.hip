@@ -7,8 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../csrc/bf16x6_kernels.h"
-#include "../tools/legacy_kernels.h"
+#include "../../speech-intent-recognizer_amd/csrc/bf16x6_kernels.h"
+#include "legacy_kernels.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
 

@@ -1,4 +1,4 @@
-// Superseded kernel generations, kept OUT of libsir_hip.so: the A/B harnesses (tools/bench_gemm.hip, tools/bench_conv.hip) include
+// Superseded kernel generations, kept OUT of libsir_hip.so: the A/B harnesses (devtools/kernel_ab/bench_gemm.hip, devtools/kernel_ab/bench_conv.hip) include
 // this header to time them against the product kernels and to compare results bitwise.  Nothing under csrc/ references them.
 //   fp32-MFMA convolutions / GEMMs / weight gradients (v_mfma_f32_32x32x2_f32), the first bf16x6 GEMM and convolution, the
 //   direct VALU conv1, the streaming and the paired fp32-FMA GRU recurrences, the L2-streaming BPTT kernel, the BatchNorm

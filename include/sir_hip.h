@@ -166,7 +166,9 @@ int sir_model_infer(sir_handle* h, const sir_model_weights* w, const float* feat
  * handle and carries on with invalid values.  sir_check_status waits for `stream`, returns SIR_ETIMEOUT if any
  * recurrence launched on this handle since the last check timed out (and clears the word), SIR_OK otherwise.
  * Call it wherever the host synchronises anyway -- once per batch of predictions (scripts/evaluate.py:85-86's
- * .cpu()) or per epoch (scripts/train.py:116's loss.item()); sir_profile_collect performs the same check. */
+ * .cpu()) or per epoch (scripts/train.py:116's loss.item()); sir_profile_collect performs the same check.
+ * The same word carries sir_ce_loss's "label outside [0, num_classes)" flag (nn.CrossEntropyLoss raises on such a
+ * target, train.py:242/:105; the kernel makes that step's loss NaN): reported here as SIR_EINVAL. */
 int sir_check_status(sir_handle* h, void* stream);
 
 /* ---- cross-batch pipelining (owned by the library) ------------------------------------------------

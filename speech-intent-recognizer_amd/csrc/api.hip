@@ -55,8 +55,8 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     h->cluster_always = getenv("SIR_CLUSTER_EVENTS") && atoi(getenv("SIR_CLUSTER_EVENTS")) == 1;   // A/B switch: chained mode throughout
     if (h->cluster_always) h->cluster_multi = true;
     h->attr_gemm_v3 = h->attr_gru_quad = h->attr_gru_bwd = h->attr_tn = h->attr_wgrad = false;
-    for (auto& x : h->xbufs) { x.p = nullptr; x.kind = 0; x.bytes = 0; x.epoch = 0; }
-    h->xbuf_next = 0;
+    for (auto& x : h->xbufs) { x.st = nullptr; x.p = nullptr; x.kind = 0; x.cap = 0; x.bytes = 0; x.epoch = 0; x.used = 0; }
+    h->xbuf_clock = 0;
     h->cfg = *cfg;
     h->cfg.window = nullptr;
     h->cfg.mel_fb = nullptr;
@@ -138,6 +138,7 @@ extern "C" int sir_destroy(sir_handle* h) {
     (void)hipFree(h->tw512); (void)hipFree(h->tw1024); (void)hipFree(h->window);
     (void)hipFree(h->melw); (void)hipFree(h->mel_desc); (void)hipFree(h->status);
     if (h->cluster_done) (void)hipEventDestroy(h->cluster_done);
+    for (auto& x : h->xbufs) (void)hipFree(x.p);
     for (auto& t : h->resample_tables) { (void)hipFree(t.taps); (void)hipFree(t.first); }
     for (auto& r : h->prof_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : h->prof_free) (void)hipEventDestroy(e);
@@ -261,9 +262,14 @@ static int check_status_impl(sir_handle* h, hipStream_t st, const char* who) {
     if (v == 0) return SIR_OK;
     SIR_HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(v), st));
     SIR_HIP_TRY(hipStreamSynchronize(st));
-    sir_set_error("%s: a GRU recurrence kernel timed out waiting for a peer workgroup of its cluster (status %u): the "
-                  "logits / gradients produced since the last check are invalid", who, v);
-    return SIR_ETIMEOUT;
+    if (v & 1u) {
+        sir_set_error("%s: a GRU recurrence kernel timed out waiting for a peer workgroup of its cluster (status %u): the "
+                      "logits / gradients produced since the last check are invalid", who, v);
+        return SIR_ETIMEOUT;
+    }
+    sir_set_error("%s: sir_ce_loss saw a label outside [0, num_classes) (status %u): that step's loss is NaN and its "
+                  "gradients are invalid (nn.CrossEntropyLoss raises on such a target)", who, v);
+    return SIR_EINVAL;
 }
 
 extern "C" int sir_check_status(sir_handle* h, void* stream) {

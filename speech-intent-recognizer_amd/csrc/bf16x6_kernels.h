@@ -85,7 +85,7 @@ constexpr int XB_ROW = 80;                                  // bytes per LDS row
 // the MFMAs (a piece costs the issuing wave ~100 cycles): waves 0-3 during step 0, their SIMD partners
 // 4-7 during step 1, so one wave per SIMD always feeds the matrix pipe.  blockIdx is remapped so that
 // the column blocks sharing an A row block run on the same XCD.  240 workgroups for the 6400 x 1536
-// projections: one round on 256 CUs.  Measured (tools/bench_gemm.hip, random operands): 107 us at
+// projections: one round on 256 CUs.  Measured (devtools/kernel_ab/bench_gemm.hip, random operands): 107 us at
 // K = 1024 (188 TF algorithmic) against 159 us for the first kernel; the kernel without any staging
 // runs 94 us and a pure-MFMA probe of the same instruction mix 69 us (1.75 PF executed).
 // ------------------------------------------------------------------------------------------
@@ -99,7 +99,7 @@ typedef __attribute__((address_space(1))) const void* sir_gptr_t;
 typedef __attribute__((address_space(3))) void* sir_lptr_t;
 constexpr int G3_DEFAULT = 16;                              // product configuration of the KNOCK template word: SPREAD = 2
 
-// KNOCK: experiment word of tools/bench_gemm.hip.  bit 0 = no staging, bit 2 = no MFMAs (timing only), bits 3-4 = SPREAD,
+// KNOCK: experiment word of devtools/kernel_ab/bench_gemm.hip.  bit 0 = no staging, bit 2 = no MFMAs (timing only), bits 3-4 = SPREAD,
 // bit 5 = PREF (see below)
 template <int KNOCK = G3_DEFAULT>
 static __global__ __launch_bounds__(512) void gemm_nt_bf16x6_v3_kernel(
@@ -307,7 +307,7 @@ static __global__ void prep_conv_wT_bf16x3_kernel(const float* __restrict__ w, u
 //   weight fragments are private (3 x 16 B per lane and tap, prefetched one tap ahead) and the pixel
 //   fragments, which every wave needs, come from the shared LDS tile.  Same tile, LDS image, MFMA
 //   order per accumulator and epilogues as the first kernel: results are bit-identical.
-//   KNOCK (tools/bench_conv.hip timing experiments; 0 in the product): bit 0 = weights loaded once,
+//   KNOCK (devtools/kernel_ab/bench_conv.hip timing experiments; 0 in the product): bit 0 = weights loaded once,
 //   bit 1 = input tile staged once.
 // ------------------------------------------------------------------------------------------
 // MINB = workgroups per CU the register allocation must allow (3 where the accumulators leave room)

@@ -56,7 +56,7 @@ static __global__ void prep_conv_w_wino_bf16x3_kernel(const float* __restrict__ 
 }
 
 // grid (ceil(ceil(W / 2) / 2), ceil(H / 32), B): one block of 16 x 2 tiles per workgroup
-// KNOCK (tools/bench_conv.hip timing experiments, results invalid; 0 in the product): bit 0 = no patch loads, bit 1 = no
+// KNOCK (devtools/kernel_ab/bench_conv.hip timing experiments, results invalid; 0 in the product): bit 0 = no patch loads, bit 1 = no
 // transform / split / LDS writes, bit 2 = no MFMAs, bit 3 = no output stores
 template <int CIN, int COUT, int OUT_MODE, int MINB = 3, int XCD_REMAP = 1, int KNOCK = 0>
 __global__ __launch_bounds__(256, MINB) void conv3x3_wino_bf16x6_kernel(

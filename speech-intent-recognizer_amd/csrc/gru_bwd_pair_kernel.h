@@ -143,7 +143,7 @@ __global__ __launch_bounds__(GP_THREADS) void gru_bwd_pair_kernel(
             unsigned spins = 0;
             while ((unsigned)((pv = __hip_atomic_load(gpeer + rp * GP_UH + kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tagv) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > GP_SPIN_LIMIT) { __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if (++spins > GP_SPIN_LIMIT) { __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
             dhs[rp * GP_UH + kp] = vown + __uint_as_float((unsigned)pv);     // (dhs was last read before the barrier above)
         }

@@ -3,19 +3,21 @@
 // constraints cost ~180 spilled VGPRs in this register-resident kernel.
 #include "gru_bwd_pair_kernel.h"
 
-size_t sir_gru_bwd_xbuf_bytes(int batch) { return (size_t)((batch + GP_BW - 1) / GP_BW) * 2 * 2 * 2 * GP_BW * GP_UH * 8; }
-
 int sir_launch_gru_bwd_pair(sir_handle* h, hipStream_t st, const float* dy, const float* gates, const float* y, const float* whh0,
-                            const float* whh1, float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S, float* xbuf) {
+                            const float* whh1, float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S) {
     if (!h->attr_gru_bwd) {
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_bwd_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GBP_LDS_BYTES));
         h->attr_gru_bwd = true;
     }
     const size_t npairs = (B + GP_BW - 1) / GP_BW;
     unsigned epoch = 0;
-    if (sir_xbuf_epoch(h, st, xbuf, 2, npairs * 2 * 2 * 2 * GP_BW * GP_UH * 8, 0xFFFFu, &epoch) != SIR_OK) return SIR_EHIP;
+    void* xbuf = nullptr;
+    if (sir_xbuf_acquire(h, st, 2, npairs * 2 * 2 * 2 * GP_BW * GP_UH * 8, 0xFFFFu, &xbuf, &epoch) != SIR_OK) {
+        sir_set_error("gru_bwd_pair: exchange buffer allocation failed");
+        return SIR_EHIP;
+    }
     hipLaunchKernelGGL(gru_bwd_pair_kernel, dim3((unsigned)(npairs * 2), 2), dim3(GP_THREADS), GBP_LDS_BYTES, st, dy, gates, y, whh0, whh1, dgi,
-                       dgh, bsum_i, bsum_h, B, S, xbuf, h->status, epoch);
+                       dgh, bsum_i, bsum_h, B, S, (float*)xbuf, h->status, epoch);
     SIR_HIP_TRY(hipGetLastError());
     return SIR_OK;
 }

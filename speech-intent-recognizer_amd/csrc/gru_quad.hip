@@ -2,14 +2,8 @@
 #include <stdlib.h>
 #include "gru_quad_kernel.h"
 
-static size_t gru_quad_xbuf_bytes(int batch) { return (size_t)((batch + GQ_NU - 1) / GQ_NU) * 2 * GQ_XBUF_PER_CLUSTER; }
-// forward granules first, the BPTT kernel's region behind them: the two formats never share bytes, so neither kernel can
-// ever mistake the other's stale granule for its own tag
-size_t sir_gru_xbuf_bytes(int batch) { return sir_gru_bwd_xbuf_offset(batch) + sir_gru_bwd_xbuf_bytes(batch); }
-size_t sir_gru_bwd_xbuf_offset(int batch) { return sir_align_up(gru_quad_xbuf_bytes(batch), 256); }
-
 int sir_launch_gru_quad(sir_handle* h, hipStream_t st, bool save, const float* gi, const float* whh0, const float* whh1, const float* bhh0,
-                        const float* bhh1, float* y, int B, int S, float* gates, float* xbuf, unsigned short* yplanes, const void* wfrag0,
+                        const float* bhh1, float* y, int B, int S, float* gates, unsigned short* yplanes, const void* wfrag0,
                         const void* wfrag1) {
     if (!h->attr_gru_quad) {
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_quad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GQ_LDS_BYTES));
@@ -19,7 +13,11 @@ int sir_launch_gru_quad(sir_handle* h, hipStream_t st, bool save, const float* g
     if (S >= 511) { sir_set_error("gru_quad: %d steps exceed the 9-bit step field of the granule tag", S); return SIR_EUNSUPPORTED; }
     const int clusters = ((B + GQ_NU - 1) / GQ_NU) * 2;
     unsigned epoch = 0;
-    if (sir_xbuf_epoch(h, st, xbuf, 1, (size_t)clusters * GQ_XBUF_PER_CLUSTER, 127u, &epoch) != SIR_OK) return SIR_EHIP;
+    void* xbuf = nullptr;
+    if (sir_xbuf_acquire(h, st, 1, (size_t)clusters * GQ_XBUF_PER_CLUSTER, 127u, &xbuf, &epoch) != SIR_OK) {
+        sir_set_error("gru_quad: exchange buffer allocation failed");
+        return SIR_EHIP;
+    }
     const dim3 grid(4, (unsigned)clusters);
     // SIR_GRU_DBG: timing knock-outs and fault injection of gru_quad_kernel (see its `dbg` comment); 0 in production
     static const int dbg = getenv("SIR_GRU_DBG") ? atoi(getenv("SIR_GRU_DBG")) : 0;

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
                 if (ok || (dbg & 1) || timed_out) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > ((dbg & 16) ? 4096u : GQ_SPIN_LIMIT)) {      // give up for good: later steps do not spin again
-                    __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     timed_out = true;
                     break;
                 }

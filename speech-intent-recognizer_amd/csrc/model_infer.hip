@@ -20,7 +20,7 @@ enum WsBuf {
     WS_XS,       // bf16x3 planes of the current GEMM A operand, [3][B*S][1024] bf16
     WS_WS,       // bf16x3 planes of W_ih: l0 [2][3][768][1024], l1 [2][3][768][512]
     WS_WCB,      // bf16x3 planes of the conv2 / conv3 weights
-    WS_GXB,      // GRU recurrence: exchange granules of the clusters
+    WS_GXB,      // (unused: the exchange granules of the GRU clusters live in handle-owned buffers, sir_xbuf_acquire)
     WS_GFL,      // (unused)
     WS_COUNT
 };
@@ -51,7 +51,7 @@ void ws_sizes(const Dims& d, size_t* bytes) {
     bytes[WS_XS] = B * d.S * 1024 * 3 * 2;
     bytes[WS_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512) * 2;
     bytes[WS_WCB] = ((size_t)3 * 32 * 16 * 64 + (size_t)3 * 64 * 9 * 128) * 2;     // conv2: 16 Winograd frequencies per (cout, cin); conv3: 9 taps
-    bytes[WS_GXB] = sir_gru_xbuf_bytes(d.B);
+    bytes[WS_GXB] = 0;
     bytes[WS_GFL] = 0;
 }
 
@@ -120,7 +120,6 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     unsigned short* wsl1 = wsl0 + (size_t)2 * 3 * 768 * 1024;
     unsigned short* wcb2 = (unsigned short*)(ws + off[WS_WCB]);
     unsigned short* wcb3 = wcb2 + (size_t)3 * 32 * 16 * 64;
-    float* gxb = (float*)(ws + off[WS_GXB]);
     const int B = d.B, S = d.S;
 
     // ---- weight preparation -------------------------------------------------------------
@@ -181,7 +180,7 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
         SirProfScope prof(h, SIR_K_GRU0, st);
         if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
         // layer 0 also writes the bf16x3 planes of ITS output: the A operand of the layer-1 projection
-        const int rc = sir_launch_gru_quad(h, st, false, gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S, nullptr, gxb,
+        const int rc = sir_launch_gru_quad(h, st, false, gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S, nullptr,
                                            xs, wht, (unsigned char*)wht + (size_t)768 * 256 * 6);
         if (rc != SIR_OK) return rc;
         if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP;
@@ -194,7 +193,7 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     {
         SirProfScope prof(h, SIR_K_GRU1, st);
         if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
-        const int rc = sir_launch_gru_quad(h, st, false, gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], y1, B, S, nullptr, gxb,
+        const int rc = sir_launch_gru_quad(h, st, false, gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], y1, B, S, nullptr,
                                            nullptr, (unsigned char*)wht + (size_t)2 * 768 * 256 * 6, (unsigned char*)wht + (size_t)3 * 768 * 256 * 6);
         if (rc != SIR_OK) return rc;
         if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP;

@@ -21,7 +21,7 @@ enum TrainBuf {
     TB_XS,        // bf16x3 planes of the forward GEMM A operand [3][B*S][1024]
     TB_WS,        // bf16x3 planes of W_ih (l0 [2][3][768][1024], l1 [2][3][768][512])
     TB_WCB,       // bf16x3 conv weights: conv2, conv3 forward, then conv2, conv3 data-gradient forms
-    TB_GXB,       // paired GRU exchange granules
+    TB_GXB,       // (unused: exchange granules live in handle-owned buffers, sir_xbuf_acquire)
     TB_GFL,       // paired GRU status word
     TB_C1M,       // conv1 input moments: 54 doubles (conv1_moments_kernel), forward -> backward
     TB_COUNT
@@ -114,7 +114,7 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     n[TB_XS] = (B * S * 1024 * 3 + 1) / 2;                       // ushort count / 2 (sizes are in floats)
     n[TB_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512 + 1) / 2;
     n[TB_WCB] = ((size_t)(3 * 32 * 16 * 64 + 3 * 32 * 9 * 64) + (size_t)2 * 3 * 64 * 9 * 128 + 1) / 2;   // conv2 forward in Winograd form (16 frequencies)
-    n[TB_GXB] = sir_gru_xbuf_bytes(d.B) / 4;
+    n[TB_GXB] = 64;
     n[TB_GFL] = 64;
     n[TB_C1M] = 2 * C1_NMOM;
 }
@@ -137,7 +137,6 @@ struct TPtrs {
     float *dy1, *dy0, *dgi, *dgh, *dx0, *dz3, *da2, *dz2, *da1, *small, *slab;
     float2* stats;
     unsigned short *xs, *wsl0, *wsl1, *wcb2, *wcb3, *wcb2t, *wcb3t;
-    float* gxb;
     unsigned int* gfl;
     double* c1m;
 };
@@ -160,7 +159,7 @@ TPtrs carve(void* ws, const size_t* off) {
     p.wsl0 = (unsigned short*)(b + off[TB_WS]); p.wsl1 = p.wsl0 + (size_t)2 * 3 * 768 * 1024;
     p.wcb2 = (unsigned short*)(b + off[TB_WCB]); p.wcb3 = p.wcb2 + (size_t)3 * 32 * 16 * 64;
     p.wcb2t = p.wcb3 + (size_t)3 * 64 * 9 * 128; p.wcb3t = p.wcb2t + (size_t)3 * 32 * 9 * 64;
-    p.gxb = (float*)(b + off[TB_GXB]); p.gfl = (unsigned int*)(b + off[TB_GFL]);
+    p.gfl = (unsigned int*)(b + off[TB_GFL]);
     p.c1m = (double*)(b + off[TB_C1M]);
     return p;
 }
@@ -289,7 +288,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
                        (const unsigned short*)(p.wsl0 + (size_t)3 * 768 * 1024), w->gru_b_ih[0], w->gru_b_ih[1], p.gi, 1536, M, 768, 1024)); }
     { SirProfScope prof(h, SIR_K_T_GRU0, st);
     if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
-    rc = sir_launch_gru_quad(h, st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0, p.gxb);
+    rc = sir_launch_gru_quad(h, st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0);
     if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP; }
     if (rc != SIR_OK) return rc;
     const float* y0in = p.y0;
@@ -305,7 +304,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
                        (const unsigned short*)(p.wsl1 + (size_t)3 * 768 * 512), w->gru_b_ih[2], w->gru_b_ih[3], p.gi, 1536, M, 768, 512)); }
     { SirProfScope prof(h, SIR_K_T_GRU1, st);
     if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
-    rc = sir_launch_gru_quad(h, st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1, p.gxb);
+    rc = sir_launch_gru_quad(h, st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1);
     if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP; }
     if (rc != SIR_OK) return rc;
     SirProfScope prof_head(h, SIR_K_T_HEAD, st);
@@ -322,10 +321,10 @@ extern "C" int sir_ce_loss(sir_handle* h, const float* logits, const int64_t* la
     SirProfScope prof(h, SIR_K_CE, (hipStream_t)stream_);
     if (num_classes <= 32)
         hipLaunchKernelGGL(ce_loss_kernel<32>, dim3(1), dim3(256), 0, (hipStream_t)stream_, logits, (const long long*)labels, batch,
-                           num_classes, loss, dlogits, grad_scale);
+                           num_classes, loss, dlogits, grad_scale, h->status);
     else
         hipLaunchKernelGGL(ce_loss_kernel<64>, dim3(1), dim3(256), 0, (hipStream_t)stream_, logits, (const long long*)labels, batch,
-                           num_classes, loss, dlogits, grad_scale);
+                           num_classes, loss, dlogits, grad_scale, h->status);
     KCHECK();
     return SIR_OK;
 }
@@ -380,7 +379,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         { SirProfScope prof(h, layer ? SIR_K_B_GRU1 : SIR_K_B_GRU0, st);
         if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
         rc = sir_launch_gru_bwd_pair(h, st, dy, gates, yout, w->gru_w_hh[2 * layer], w->gru_w_hh[2 * layer + 1], p.dgi, p.dgh, bsum_i, bsum_h,
-                                     B, S, p.gxb + sir_gru_bwd_xbuf_offset(B) / 4);
+                                     B, S);
         if (rc != SIR_OK) return rc;
         if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP;
         // bias gradients first: bsum_* alias the slab area used below

@@ -25,6 +25,7 @@ enum SirKernelId {
 };
 
 struct SirProfRec { int id; hipEvent_t e0, e1; };
+static inline size_t sir_align_up_sz(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // polyphase resampling filter of one (orig_freq, new_freq) pair (frontend.hip), device tables
 struct sir_resample_table {
@@ -72,33 +73,53 @@ struct sir_handle {
     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) latches, per handle = per device (a process-wide static would skip
     // the second device of a process that drives several)
     bool attr_gemm_v3, attr_gru_quad, attr_gru_bwd, attr_tn, attr_wgrad;
-    // exchange-granule buffers of the cluster kernels seen by this handle: {buffer, kind, bytes the previous launch on it
-    // covered, launch epoch}.  The epoch goes into every granule's tag, so a buffer is
-    // zeroed when it is new to the handle or needs more bytes than before -- not before every launch (4.8 us each, 4 per
-    // training step / 2 per inference batch, serialised in front of a latency-bound kernel).
-    struct XbufEntry { const void* p; int kind; size_t bytes; unsigned epoch; };
-    XbufEntry xbufs[8];
-    int xbuf_next;
+    // Exchange-granule buffers of the cluster kernels (GRU recurrences).  They are OWNED by the handle (hipMalloc), one per
+    // (launch stream, kernel kind): nothing but that kernel ever writes them, so a granule found there is always one of its
+    // own from an earlier launch and the launch epoch in its tag tells it apart.  (They used to be carved out of the caller's
+    // workspace at a batch-dependent offset: a launch at another batch size, or any other tenant of that memory, could leave
+    // arbitrary bits where the 16-bit tag of the forward kernel is polled.)  Launches on one stream are ordered, launches on
+    // different streams get different buffers.  A buffer is zeroed when it is new or must cover more bytes than the
+    // previous launch on it wrote -- not before every launch (4.8 us each, 4 per training step / 2 per inference batch,
+    // serialised in front of a latency-bound kernel).
+    struct XbufEntry { hipStream_t st; int kind; void* p; size_t cap, bytes; unsigned epoch; unsigned long long used; };
+    XbufEntry xbufs[16];
+    unsigned long long xbuf_clock;
 };
 
-// launch epoch for a cluster kernel's granule buffer; zeroes it first when needed.  `kind` separates kernels that share
-// one buffer with different granule formats (their tags cannot match each other's: gru_quad_kernel.h / gru_bwd_pair_kernel.h)
-static inline int sir_xbuf_epoch(sir_handle* h, hipStream_t st, void* xbuf, int kind, size_t bytes, unsigned mask, unsigned* epoch) {
+// granule buffer + launch epoch for a cluster kernel launched on `st`; allocates / grows / zeroes the buffer when needed.
+// `kind` separates kernels with different granule formats (gru_quad_kernel.h / gru_bwd_pair_kernel.h).
+static inline int sir_xbuf_acquire(sir_handle* h, hipStream_t st, int kind, size_t bytes, unsigned mask, void** xbuf, unsigned* epoch) {
     sir_handle::XbufEntry* e = nullptr;
     for (auto& x : h->xbufs)
-        if (x.p == xbuf && x.kind == kind) e = &x;
-    if (!e) {
-        e = &h->xbufs[h->xbuf_next];
-        h->xbuf_next = (h->xbuf_next + 1) % 8;
-        e->p = xbuf; e->kind = kind; e->bytes = 0; e->epoch = 0;
+        if (x.p && x.st == st && x.kind == kind) e = &x;
+    if (!e) {                                             // free slot, else the least recently used one
+        e = &h->xbufs[0];
+        for (auto& x : h->xbufs) {
+            if (!x.p) { e = &x; break; }
+            if (x.used < e->used) e = &x;
+        }
+        if (e->p) {                                       // hipFree waits for the device: no launch can still be using it
+            if (hipFree(e->p) != hipSuccess) return SIR_EHIP;
+            e->p = nullptr;
+        }
+        e->st = st; e->kind = kind; e->cap = 0; e->bytes = 0; e->epoch = 0;
+    }
+    if (bytes > e->cap) {
+        if (e->p && hipFree(e->p) != hipSuccess) return SIR_EHIP;
+        e->p = nullptr; e->cap = 0; e->bytes = 0;
+        const size_t cap = sir_align_up_sz(bytes, (size_t)1 << 20);
+        if (hipMalloc(&e->p, cap) != hipSuccess) { e->p = nullptr; return SIR_EHIP; }
+        e->cap = cap;
     }
     // new buffer, or more clusters than the PREVIOUS launch on it wrote: the extra granules are older than one epoch (after a
     // run of 128 smaller batches they would carry the current epoch again) -- zero.  Otherwise every granule that will be
     // polled was written by the previous launch, whose epoch differs.
-    if (bytes > e->bytes && hipMemsetAsync(xbuf, 0, bytes, st) != hipSuccess) return SIR_EHIP;
+    if (bytes > e->bytes && hipMemsetAsync(e->p, 0, bytes, st) != hipSuccess) return SIR_EHIP;
     e->bytes = bytes;
     e->epoch = (e->epoch + 1) & mask;
+    e->used = ++h->xbuf_clock;
     *epoch = e->epoch;
+    *xbuf = e->p;
     return SIR_OK;
 }
 
@@ -175,12 +196,9 @@ int sir_features_launch(sir_handle* h, const void* wave, int wave_dtype, int64_t
 
 // GRU recurrences (gru_quad.hip: forward, clusters of four workgroups on the matrix cores; gru_pair.hip: BPTT, pairs of
 // workgroups).  Both write h->status if an exchange spin times out.
-size_t sir_gru_xbuf_bytes(int batch);          // exchange-granule workspace: forward region + BPTT region
-size_t sir_gru_bwd_xbuf_offset(int batch);     // byte offset of the BPTT kernel's region
-size_t sir_gru_bwd_xbuf_bytes(int batch);
 int sir_launch_gru_quad(sir_handle* h, hipStream_t st, bool save, const float* gi, const float* whh0, const float* whh1, const float* bhh0,
-                        const float* bhh1, float* y, int B, int S, float* gates, float* xbuf,
+                        const float* bhh1, float* y, int B, int S, float* gates,
                         unsigned short* yplanes = nullptr, const void* wfrag0 = nullptr, const void* wfrag1 = nullptr);
 void sir_prep_whh_quad(hipStream_t st, const float* whh, void* frag);     // -> 768 * 256 * 6 bytes
 int sir_launch_gru_bwd_pair(sir_handle* h, hipStream_t st, const float* dy, const float* gates, const float* y, const float* whh0,
-                            const float* whh1, float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S, float* xbuf);
+                            const float* whh1, float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S);

@@ -252,14 +252,19 @@ static __global__ __launch_bounds__(256) void dropout_split3_kernel(const float*
 template <int CMAX>
 static __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
                                                        int B, int C, float* __restrict__ loss, float* __restrict__ dlogits,
-                                                       float grad_scale) {
+                                                       float grad_scale, unsigned int* status) {
     __shared__ float red[256];
     float acc = 0.0f;
     for (int b = threadIdx.x; b < B; b += 256) {
         // the row goes into registers with ALL its loads in flight (C <= CMAX, dispatched by the host): the per-class loops of
         // the first version waited for one dependent load after the other, 15 us for 256 x 31 logits
         const float* r = logits + (size_t)b * C;
-        const int y = (int)labels[b];
+        // a label outside [0, C) (nn.CrossEntropyLoss raises on it; train.py:242): flag the handle's status word (bit 1 ->
+        // SIR_EINVAL at the next sir_check_status) and make the loss NaN instead of reading out of bounds
+        const long long yl = labels[b];
+        const bool bad = yl < 0 || yl >= (long long)C;
+        if (bad) __hip_atomic_fetch_or(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int y = bad ? 0 : (int)yl;
         float v[CMAX];
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) v[c] = c < C ? r[c] : 0.0f;
@@ -271,7 +276,7 @@ static __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __rest
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = expf(v[c] - mx); den += v[c]; }
         const float lse = mx + logf(den);
-        acc += lse - ry;
+        acc += bad ? __builtin_nanf("") : lse - ry;
         if (dlogits) {
             const float inv = 1.0f / den, gs = grad_scale / (float)B;
 #pragma unroll

@@ -46,9 +46,17 @@ class HipFeaturizer:
         self._h = C.c_void_p()
         _native.check(_native.lib().sir_create(C.byref(cfg), C.byref(self._h)), "sir_create")
         self._ws = None
+        self._pins = 0          # library objects (sir_pipeline) created from this handle that are still alive
+
+    def pin(self):
+        """Called by whoever creates a longer-lived library object from this handle (``sir_pipeline``, kept for the life of
+        the process: sir_amd/pipeline.py): the handle must then outlive it, so ``__del__`` leaves it to process exit."""
+        self._pins += 1
 
     def __del__(self):
         try:
+            if getattr(self, "_pins", 0) > 0:
+                return
             if getattr(self, "_h", None):
                 _native.lib().sir_destroy(self._h)
                 self._h = None

@@ -116,12 +116,23 @@ class Workspace:
         return self.buf
 
 
-def check_status():
+def check_status(all_ranks=True):
     """Raise ``SirError`` if a GRU recurrence launched since the last check timed out in its inter-workgroup exchange
-    (``sir_check_status``: its outputs were invalid).  Host-synchronous on the current stream -- call it where the host
-    waits anyway (end of an epoch, after a batch of predictions has been copied back)."""
+    (``sir_check_status``: its outputs were invalid) or ``sir_ce_loss`` met a label outside ``[0, num_classes)``.
+    Host-synchronous on the current stream -- call it where the host waits anyway (end of an epoch, after a batch of
+    predictions has been copied back).  In a data-parallel job the flag is MAX-reduced over the ranks first, so that
+    EVERY rank raises (a rank that raised alone would leave the others blocked in the next collective until the RCCL
+    timeout); every rank must therefore call it at the same point."""
+    import torch.distributed as dist
     lib = _native.lib()
-    _native.check(lib.sir_check_status(get_featurizer().handle, _native.current_stream_ptr()), "sir_check_status")
+    rc = lib.sir_check_status(get_featurizer().handle, _native.current_stream_ptr())
+    if all_ranks and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        flag = torch.tensor([1 if rc != _native.SIR_OK else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if rc == _native.SIR_OK and int(flag.item()):
+            raise _native.SirError("sir_check_status failed on another rank of this job (a GRU recurrence timed out or a "
+                                   "label was out of range there): this rank stops with it")
+    _native.check(rc, "sir_check_status")
 
 
 def _as_features(x):

@@ -24,8 +24,10 @@ def _library_pipeline(n):
     key = (torch.cuda.current_device(), n)
     if key not in _pipelines:
         p = C.c_void_p()
-        _native.check(_native.lib().sir_pipeline_create(get_featurizer().handle, n, C.byref(p)), "sir_pipeline_create")
-        _pipelines[key] = (p, {})          # handle, raw hipStream_t -> torch ExternalStream
+        fz = get_featurizer()
+        _native.check(_native.lib().sir_pipeline_create(fz.handle, n, C.byref(p)), "sir_pipeline_create")
+        fz.pin()                           # the sir_handle must outlive the pipeline made from it
+        _pipelines[key] = (p, {}, fz)      # handle, raw hipStream_t -> torch ExternalStream, the pinned featurizer
     return _pipelines[key]
 
 
@@ -44,7 +46,7 @@ class BatchPipeline:
         self.model = model
         self.n = max(1, int(n_streams))
         self._lib = _native.lib()
-        self._p, self._ext = _library_pipeline(self.n)
+        self._p, self._ext = _library_pipeline(self.n)[:2]
         self.featurizer = get_featurizer()
         self.workspaces = [model._ws] + [ops.Workspace() for _ in range(self.n - 1)]
         self._cur = None                   # (batch index, slot, torch stream) of the open submission

@@ -26,6 +26,12 @@ from torch.utils.data import Dataset, get_worker_info
 logger = logging.getLogger(__name__)
 
 
+class WorkerCacheMiss(RuntimeError):
+    """A DataLoader worker was asked for a clip that is neither cached nor pre-extracted: the GPU cannot be used from a
+    worker process.  The only exception ``FSCIntentDataset.extract_features`` lets through (everything else is logged and
+    becomes a zero spectrogram, dataset.py:156-158)."""
+
+
 def mask_along_axis(spec, mask_param, axis, mask_value=0.0):
     """Band mask with torchaudio's ``mask_along_axis`` draw (TimeMasking / FrequencyMasking,
     dataset.py:69-71): v = rand*param, s = rand*(size - v), mask [floor(s), floor(s)+floor(v))."""
@@ -145,7 +151,7 @@ class FSCIntentDataset(Dataset):
                 return zeros
             if get_worker_info() is not None:
                 # (not reachable when the dataset was built on a GPU box: the constructor extracted every miss)
-                raise RuntimeError(f"{audio_path}: not in the feature cache and the GPU cannot be used from a DataLoader "
+                raise WorkerCacheMiss(f"{audio_path}: not in the feature cache and the GPU cannot be used from a DataLoader "
                                    "worker process; call dataset.prefetch_missing() in the main process, run "
                                    "scripts.precompute_features, or use num_workers=0")
             from sir_amd.scripts.precompute_features import AudioFeatureExtractor
@@ -153,9 +159,9 @@ class FSCIntentDataset(Dataset):
                 self._extractor = AudioFeatureExtractor(self.sample_rate, self.n_mels, 1024, 512)
             feat = self._extractor.extract_features(audio_path, max_duration=5.0)
             return feat if feat is not None else zeros
-        except RuntimeError:
+        except WorkerCacheMiss:             # a set-up error of the job, not a bad clip: must not turn into silent zeros
             raise
-        except Exception as e:
+        except Exception as e:              # everything else (corrupt / undecodable file, HIP error): log + zeros (dataset.py:156-158)
             logger.error(f"Error processing {audio_path}: {str(e)}")
             return zeros
 

@@ -83,10 +83,8 @@ def train_epoch(model, train_loader, optimizer, criterion, device, scaler=None):
         if batch_idx % 10 == 0 and not _quiet():
             pbar.set_postfix({"loss": f"{loss.item():.4f}",
                               "GPU": f"{torch.cuda.memory_allocated() / 1024 ** 2:.1f}MB"})
-    if not losses:
-        return 0.0
-    mean = torch.stack(losses).mean().item()          # one device->host sync per epoch
-    ops.check_status()                                # ... which is where a timed-out GRU recurrence is reported
+    mean = torch.stack(losses).mean().item() if losses else 0.0      # one device->host sync per epoch
+    ops.check_status()            # ... which is where a timed-out GRU recurrence is reported (on every rank: collective)
     return mean
 
 
@@ -132,9 +130,7 @@ def train_epoch_waveforms(model, wave_loader, optimizer, criterion, device, t_pa
             step()
     while pending:
         step()
-    if not losses:
-        return 0.0
-    mean = torch.stack(losses).mean().item()
+    mean = torch.stack(losses).mean().item() if losses else 0.0
     ops.check_status()
     return mean
 

@@ -21,6 +21,10 @@ from .featurizer import get_featurizer
 _seed_counter = itertools.count(1)
 OVERLAP_GRAD_EXCHANGE = os.environ.get("SIR_DDP_OVERLAP", "1") != "0"
 HAND_OVER_GRADS = os.environ.get("SIR_HAND_OVER_GRADS", "1") != "0"
+# take the data-parallel exchange path even in a ONE-rank process group (bench.py's `rccl_world1` leg and the nccl tests
+# on a one-GPU box: the collectives, their stream ordering against the backward kernels and the final scale all run;
+# the sum over one rank is the identity)
+FORCE_EXCHANGE = os.environ.get("SIR_DDP_FORCE", "0") == "1"
 
 
 def dropout_seed(step_counter, rank=None):
@@ -153,11 +157,12 @@ class _TrainStep(torch.autograd.Function):
 def _exchange_and_scale(grads, run):
     """The per-step gradient exchange around the two halves of the backward (``run(part)`` launches one half, or
     nothing for a rank that has no batch)."""
+    import torch.distributed as dist
     world = world_size()
-    if world > 1 and OVERLAP_GRAD_EXCHANGE:
+    forced = FORCE_EXCHANGE and dist.is_available() and dist.is_initialized()
+    if (world > 1 or forced) and OVERLAP_GRAD_EXCHANGE:
         # data parallel: the GRU / attention / fc gradients (96 % of the 13 MB) are final after the first half of the
         # backward; their all-reduce runs beside the conv backward, the small conv / BN bucket follows
-        import torch.distributed as dist
         run(_native.BWD_HEAD_GRU)
         tail = grads.flat[grads.n_cnn:]
         work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True)
@@ -167,7 +172,11 @@ def _exchange_and_scale(grads, run):
         grads.flat.mul_(1.0 / world)
     else:
         run(_native.BWD_ALL)
-        all_reduce_mean_(grads.flat)            # the one exchange step of data-parallel training
+        if forced:                              # un-overlapped form of the same exchange
+            dist.all_reduce(grads.flat, op=dist.ReduceOp.SUM)
+            grads.flat.mul_(1.0 / world)
+        else:
+            all_reduce_mean_(grads.flat)        # the one exchange step of data-parallel training
 
 
 def zero_contribution_step(mod):

@@ -36,6 +36,19 @@ def test_pick_json_line():
     assert bench.pick_json_line(["x\n", "{broken\n"]) is None
 
 
+def test_visible_gpu_count_reads_the_kfd_topology_without_hip(tmp_path):
+    """CPU nodes (simd_count 0) are not GPUs; *_VISIBLE_DEVICES cuts the count; a missing topology means no GPU."""
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):
+        d = tmp_path / "nodes" / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nmem_banks_count 1\n")
+    nodes = str(tmp_path / "nodes")
+    assert bench.visible_gpu_count(nodes, env={}) == 3
+    assert bench.visible_gpu_count(nodes, env={"HIP_VISIBLE_DEVICES": "0,2"}) == 2
+    assert bench.visible_gpu_count(nodes, env={"ROCR_VISIBLE_DEVICES": "1"}) == 1
+    assert bench.visible_gpu_count(str(tmp_path / "absent"), env={}) == 0
+
+
 def _run(args, env_extra):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(env_extra)
@@ -45,8 +58,7 @@ def _run(args, env_extra):
 
 def test_refuses_instead_of_degrading():
     """More ranks than visible GPUs -> exit code 2 and no result line; WORLD_SIZE != --gpus -> the same."""
-    import torch
-    if torch.cuda.device_count() < 2:
+    if (bench.visible_gpu_count() or 0) < 2:
         r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"SIR_BENCH_SHARE_GPU": "0"})
         assert r.returncode == 2 and "only" in r.stderr and bench.pick_json_line(r.stdout.splitlines()) is None
     r = _run(["--gpus", "4", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
