@@ -84,6 +84,7 @@ def test_training_alternating_batch_sizes_and_scribbled_workspace(sd):
             if rnd >= 1:
                 _scribble(m._sir_train["ws"].buf)
     # and the eval path of the same module in between (its own workspace, the same handle-owned exchange buffers)
+    m.load_state_dict(sd)               # (the last training step above moved the BN running statistics)
     m.eval()
     lg0 = m(data["b"][0]).clone()
     m.train()
