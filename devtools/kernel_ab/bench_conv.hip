@@ -6,12 +6,14 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <type_traits>
 #include <vector>
 #include "../../speech-intent-recognizer_amd/csrc/bf16x6_kernels.h"
 #include "legacy_kernels.h"
 #include "../../speech-intent-recognizer_amd/csrc/conv_wino_bf16x6_kernel.h"
+#include "conv_wino2_bf16x6_kernel.h"
 
 #define CK_(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -191,6 +193,8 @@ static void run_wino(int B, int H, int W) {
         printf("  winograd knock-outs (timing only): no loads %.1f, no transform/split/LDS writes %.1f, no MFMAs %.1f, no stores %.1f, loads+transform %.1f, all but MFMA %.1f, all %.1f us\n",
                ko(integral_constant<int, 1>{}), ko(integral_constant<int, 2>{}), ko(integral_constant<int, 4>{}), ko(integral_constant<int, 8>{}),
                ko(integral_constant<int, 3>{}), ko(integral_constant<int, 11>{}), ko(integral_constant<int, 15>{}));
+        printf("  more knock-outs: weights loaded once %.1f, weights once + no patch loads %.1f, weights once + no loads + no transform %.1f us\n",
+               ko(integral_constant<int, 16>{}), ko(integral_constant<int, 17>{}), ko(integral_constant<int, 19>{}));
         for (int k = 0; k < 4; ++k) (void)hipFree(dxr[k]);
     }
     printf("  BN + ReLU + pool:  direct %.1f us (%.1f TF)   winograd %.1f us (%.1f TF algorithmic); at 3 workgroups/CU: %.1f us\n", t1, gf * 1e3 / t1, t2, gf * 1e3 / t2, t2b);
@@ -255,7 +259,133 @@ static void load_loop(double seconds) {
     }
 }
 
+// Second-generation Winograd kernel (conv_wino2_bf16x6_kernel.h) against the direct kernel: same input, same weights.
+//   MODE 0: pooled NHWC, 1: pooled GRU layout + bf16x3 planes, 2: raw + statistics, 3: raw (data gradient: DGRAD weights)
+template <int CIN, int COUT, int PR, int PC, int MODE, bool DGRAD, int MINB>
+static void run_wino2(const char* name, int B, int H, int W, int reps = 60) {
+    const int Hp = H / 2, Wp = W / 2;
+    const size_t nx = (size_t)B * H * W * CIN, nw = (size_t)COUT * CIN * 9;
+    const bool raw = MODE >= 2;
+    const size_t nout = raw ? (size_t)B * H * W * COUT : (size_t)B * Hp * Wp * COUT;
+    std::vector<float> hx(nx), hw(nw), hs(COUT), ht(COUT);
+    srand(13);
+    for (auto& v : hx) v = rand() / (float)RAND_MAX * 2.0f - 0.3f;
+    for (auto& v : hw) v = (rand() / (float)RAND_MAX - 0.5f) * 0.2f;
+    for (int c = 0; c < COUT; ++c) { hs[c] = 0.5f + rand() / (float)RAND_MAX; ht[c] = rand() / (float)RAND_MAX - 0.5f; }
+    float *dx, *dw, *ds, *dt, *o1, *o2;
+    unsigned short *wpb, *wpw, *pl1 = nullptr, *pl2 = nullptr;
+    Wino2Geo geo;
+    if (!wino2_geo(B, H, W, &geo)) { printf("%s: unsupported shape\n", name); return; }
+    const dim3 gd((W + 4 * PC - 1) / (4 * PC), (H + 8 * PR - 1) / (8 * PR), B);
+    float2 *st1 = nullptr, *st2 = nullptr;
+    CK_(hipMalloc(&dx, nx * 4)); CK_(hipMalloc(&dw, nw * 4)); CK_(hipMalloc(&ds, COUT * 4)); CK_(hipMalloc(&dt, COUT * 4));
+    CK_(hipMalloc(&o1, nout * 4)); CK_(hipMalloc(&o2, nout * 4)); CK_(hipMalloc(&wpb, nw * 6)); CK_(hipMalloc(&wpw, (size_t)COUT * CIN * 16 * 6));
+    if (MODE == 1) { CK_(hipMalloc(&pl1, nout * 6)); CK_(hipMalloc(&pl2, nout * 6)); CK_(hipMemset(pl1, 0, nout * 6)); CK_(hipMemset(pl2, 0, nout * 6)); }
+    if (MODE == 2) { CK_(hipMalloc(&st1, (size_t)gd.x * gd.y * B * COUT * 8)); CK_(hipMalloc(&st2, (size_t)geo.NS * COUT * 8)); }
+    CK_(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
+    CK_(hipMemcpy(ds, hs.data(), COUT * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(dt, ht.data(), COUT * 4, hipMemcpyHostToDevice));
+    hipStream_t st; CK_(hipStreamCreate(&st));
+    // forward: weights [COUT][CIN][3][3]; data gradient: the layer's weights are [CIN][COUT][3][3] (forward cout = this CIN)
+    if (DGRAD) {
+        hipLaunchKernelGGL(prep_conv_wT_bf16x3_kernel, dim3((CIN * 9 * COUT + 255) / 256), dim3(256), 0, st, (const float*)dw, wpb, COUT, CIN);
+        hipLaunchKernelGGL(prep_conv_wT_wino_bf16x3_kernel, dim3((CIN * 16 * COUT + 255) / 256), dim3(256), 0, st, (const float*)dw, wpw, COUT, CIN);
+    } else {
+        hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((CIN * 9 * COUT + 255) / 256), dim3(256), 0, st, (const float*)dw, wpb, CIN, COUT);
+        hipLaunchKernelGGL(prep_conv_w_wino_bf16x3_kernel, dim3((CIN * 16 * COUT + 255) / 256), dim3(256), 0, st, (const float*)dw, wpw, CIN, COUT);
+    }
+    CK_(hipMemsetAsync(o1, 0, nout * 4, st)); CK_(hipMemsetAsync(o2, 0, nout * 4, st));
+    constexpr int DM = MODE == 3 ? 2 : MODE;              // the direct kernel's raw mode
+    constexpr int DB = (PR * PC <= 8 && MINB == 2) ? 1 : 0;
+    bool attr = false;
+    auto direct = [&](const float* in) {
+        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, DM, 0, MINB, 1, DB>), gd, dim3(256), conv_ns_lds_bytes(PR, PC, DB ? 2 : 1), st, in,
+                           (const unsigned short*)wpb, (const float*)ds, (const float*)dt, o1, H, W, Hp, Wp, MODE == 1 ? (float2*)pl1 : st1); };
+    auto wino2 = [&](const float* in) {
+        CK_((launch_conv_wino2<CIN, COUT, MODE>(st, &attr, in, wpw, ds, dt, o2, B, H, W, MODE == 1 ? (float2*)pl2 : st2))); };
+    direct(dx); wino2(dx);
+    CK_(hipStreamSynchronize(st));
+    {
+        std::vector<float> h1(nout), h2(nout);
+        CK_(hipMemcpy(h1.data(), o1, nout * 4, hipMemcpyDeviceToHost)); CK_(hipMemcpy(h2.data(), o2, nout * 4, hipMemcpyDeviceToHost));
+        double d = 0, mx = 0, sq = 0; size_t bad = 0, first = (size_t)-1;
+        for (size_t i = 0; i < nout; ++i) {
+            const double e = fabs((double)h1[i] - h2[i]);
+            if (e > 1e-4) { ++bad; if (first == (size_t)-1) first = i; }
+            d = fmax(d, e); mx = fmax(mx, fabs(h1[i])); sq += (double)h1[i] * h1[i];
+        }
+        printf("%s: B=%d %dx%d %d->%d mode %d, %d tasks x %d\n  max |direct - wino2| = %.3e (max |out| %.3f, rms %.3f), %zu elements off by > 1e-4", name, B, H, W, CIN, COUT,
+               MODE, geo.NS, COUT / 64, d, mx, sqrt(sq / nout), bad);
+        if (bad) printf(" (first at %zu: %.6f vs %.6f)", first, h1[first], h2[first]);
+        printf("\n");
+        if (MODE == 1) {
+            std::vector<unsigned short> p1(nout * 3), p2(nout * 3);
+            CK_(hipMemcpy(p1.data(), pl1, nout * 6, hipMemcpyDeviceToHost)); CK_(hipMemcpy(p2.data(), pl2, nout * 6, hipMemcpyDeviceToHost));
+            // planes of slightly different floats differ in their low parts: compare the reconstructed values
+            double dp = 0;
+            for (size_t i = 0; i < nout; ++i) {
+                auto f = [](unsigned short u) { unsigned v = (unsigned)u << 16; float x; memcpy(&x, &v, 4); return (double)x; };
+                dp = fmax(dp, fabs(f(p1[i]) + f(p1[nout + i]) + f(p1[2 * nout + i]) - f(p2[i]) - f(p2[nout + i]) - f(p2[2 * nout + i])));
+            }
+            printf("  bf16x3 planes (hi + mid + lo): max difference %.3e\n", dp);
+        }
+        if (MODE == 2) {
+            const size_t n1 = (size_t)gd.x * gd.y * B, n2 = geo.NS;
+            std::vector<float2> s1(n1 * COUT), s2(n2 * COUT);
+            CK_(hipMemcpy(s1.data(), st1, s1.size() * 8, hipMemcpyDeviceToHost)); CK_(hipMemcpy(s2.data(), st2, s2.size() * 8, hipMemcpyDeviceToHost));
+            double worst = 0;
+            for (int c = 0; c < COUT; ++c) {
+                double a = 0, aq = 0, b2 = 0, bq = 0;
+                for (size_t k = 0; k < n1; ++k) { a += s1[k * COUT + c].x; aq += s1[k * COUT + c].y; }
+                for (size_t k = 0; k < n2; ++k) { b2 += s2[k * COUT + c].x; bq += s2[k * COUT + c].y; }
+                worst = fmax(worst, fmax(fabs(a - b2) / fmax(1.0, fabs(a)), fabs(aq - bq) / fmax(1.0, fabs(aq))));
+            }
+            printf("  channel statistics: worst relative difference of (sum, sum of squares) = %.3e\n", worst);
+        }
+    }
+    if (B >= 64) {
+        float* dxr[4];
+        for (int k = 0; k < 4; ++k) { CK_(hipMalloc(&dxr[k], nx * 4)); CK_(hipMemcpyAsync(dxr[k], dx, nx * 4, hipMemcpyDeviceToDevice, st)); }
+        int rot = 0;
+        const float t1 = time_us(st, reps, [&] { direct(dxr[rot++ & 3]); });
+        const float t2 = time_us(st, reps, [&] { wino2(dxr[rot++ & 3]); });
+        const double gf = 2.0 * B * H * W * (double)COUT * CIN * 9 * 1e-9;
+        printf("  rotating inputs: direct %.1f us (%.1f TF)   wino2 %.1f us (%.1f TF algorithmic)\n", t1, gf * 1e3 / t1, t2, gf * 1e3 / t2);
+        for (int k = 0; k < 4; ++k) (void)hipFree(dxr[k]);
+        // phase stamps of workgroup 0, second task (cycles relative to the first stamp): group A | group B
+        bool attr2 = false;
+        for (int rep = 0; rep < 3; ++rep)
+            CK_((launch_conv_wino2<CIN, COUT, MODE, 1>(st, &attr2, dx, wpw, ds, dt, o2, B, H, W, MODE == 1 ? (float2*)pl2 : st2)));
+        CK_(hipStreamSynchronize(st));
+        long long hs_[2][32];
+        CK_(hipMemcpyFromSymbol(hs_, HIP_SYMBOL(w2_dbg_stamps), sizeof(hs_)));
+        for (int g = 0; g < 2; ++g) {
+            printf("  stamps group %c:", g ? 'B' : 'A');
+            for (int k = 0; k < 2 * (2 * (CIN / 16) + 1) + 5 && k < 32; ++k) printf(" %lld", hs_[g][k] - hs_[0][0]);
+            printf("\n");
+        }
+    }
+    hipFree(dx); hipFree(dw); hipFree(ds); hipFree(dt); hipFree(o1); hipFree(o2); hipFree(wpb); hipFree(wpw);
+    if (pl1) hipFree(pl1); if (pl2) hipFree(pl2); if (st1) hipFree(st1); if (st2) hipFree(st2);
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "wino2") {
+        const bool small = argc > 2 && std::string(argv[2]) == "small";
+        if (!small) {
+            run_wino2<32, 64, 4, 2, 0, false, 3>("conv2 pooled", 256, 32, 100);
+            run_wino2<32, 64, 4, 2, 2, false, 3>("conv2 raw + stats", 256, 32, 100);
+            run_wino2<64, 128, 2, 2, 1, false, 2>("conv3 GRU layout + planes", 256, 16, 50);
+            run_wino2<64, 128, 2, 2, 2, false, 2>("conv3 raw + stats", 256, 16, 50);
+            run_wino2<128, 64, 2, 4, 3, true, 2>("conv3 data gradient", 256, 16, 50);
+        }
+        run_wino2<32, 64, 4, 2, 0, false, 3>("conv2 pooled, ragged", 3, 32, 47);
+        run_wino2<32, 64, 4, 2, 2, false, 3>("conv2 raw, ragged", 5, 32, 47);
+        run_wino2<64, 128, 2, 2, 1, false, 2>("conv3 GRU layout, ragged", 3, 16, 23);
+        run_wino2<64, 128, 2, 2, 2, false, 2>("conv3 raw, ragged", 1, 16, 15);
+        run_wino2<128, 64, 2, 4, 3, true, 2>("conv3 data gradient, ragged", 5, 16, 23);
+        return 0;
+    }
     if (argc > 1 && std::string(argv[1]) == "loop") { load_loop(argc > 2 ? atof(argv[2]) : 3.0); return 0; }
     if (argc > 1 && std::string(argv[1]) == "wino") { run_wino(256, 32, 100); run_wino(3, 32, 47); return 0; }
     run<64, 128, 2, 4, 1>("conv3", 256, 16, 50);

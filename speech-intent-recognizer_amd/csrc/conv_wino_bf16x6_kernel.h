@@ -57,7 +57,7 @@ static __global__ void prep_conv_w_wino_bf16x3_kernel(const float* __restrict__ 
 
 // grid (ceil(ceil(W / 2) / 2), ceil(H / 32), B): one block of 16 x 2 tiles per workgroup
 // KNOCK (devtools/kernel_ab/bench_conv.hip timing experiments, results invalid; 0 in the product): bit 0 = no patch loads, bit 1 = no
-// transform / split / LDS writes, bit 2 = no MFMAs, bit 3 = no output stores
+// transform / split / LDS writes, bit 2 = no MFMAs, bit 3 = no output stores, bit 4 = weight fragments loaded once per workgroup
 template <int CIN, int COUT, int OUT_MODE, int MINB = 3, int XCD_REMAP = 1, int KNOCK = 0>
 __global__ __launch_bounds__(256, MINB) void conv3x3_wino_bf16x6_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpb, const float* __restrict__ scale,
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_wino_bf16x6_kernel(
                 a[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(afrag + p * PLB + ff * FB));
                 bq[p] = __builtin_bit_cast(bf16x8, wq[ff % WPF][p]);
             }
-            load_w(gnext, wq[ff % WPF]);
+            if (!(KNOCK & 16)) load_w(gnext, wq[ff % WPF]);      // KNOCK bit 4: weights loaded once per workgroup (timing only)
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
             if (KNOCK & 4) {
                 Wa[il][j & 1][0] += __builtin_bit_cast(float4, a[0]).x * __builtin_bit_cast(float4, bq[1]).y + __builtin_bit_cast(float4, a[2]).x + __builtin_bit_cast(float4, bq[2]).x + __builtin_bit_cast(float4, a[1]).x + __builtin_bit_cast(float4, bq[0]).x;
