@@ -66,34 +66,6 @@ constexpr int W2_XCH_BYTES = 2 * 16 * 1024;                 // hand-over of the 
 constexpr int W2_LDS_BYTES = 2 * W2_V_BYTES + 2 * W2_RAW_BYTES + W2_XCH_BYTES;   // 157,696
 constexpr int W2_PPW = (W2_RAW_PIECES + 3) / 4;             // DMA pieces per wave of group B
 
-// U = G g G^T of the DATA-GRADIENT convolution (channel roles swapped, taps flipped: cf. prep_conv_wT_bf16x3_elem) as
-// bf16x3 planes wpb[plane][(co_f / 16) * 16 + f][ci_f][co_f % 16]; "output" channels = forward INPUT channels
-__device__ __forceinline__ void prep_conv_wT_wino_bf16x3_elem(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin_f, int cout_f, int idx) {
-    const int total = cout_f * 16 * cin_f;
-    if (idx >= total) return;
-    const int e = idx & 15, cop = (idx >> 4) % cin_f, g = (idx >> 4) / cin_f;
-    const int co_f = (g / 16) * 16 + e, f = g % 16, i = f >> 2, j = f & 3;
-    const float* gk = w + ((size_t)co_f * cin_f + cop) * 9;
-    const float Gm[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
-    float u = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        float t = 0.0f;
-#pragma unroll
-        for (int l = 0; l < 3; ++l) t = fmaf(gk[8 - (k * 3 + l)], Gm[j][l], t);
-        u = fmaf(Gm[i][k], t, u);
-    }
-    if (j == 3) u = -u;
-    unsigned short h, m, l;
-    split3(u, h, m, l);
-    wpb[idx] = h;
-    wpb[(size_t)total + idx] = m;
-    wpb[2 * (size_t)total + idx] = l;
-}
-static __global__ void prep_conv_wT_wino_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin_f, int cout_f) {
-    prep_conv_wT_wino_bf16x3_elem(w, wpb, cin_f, cout_f, blockIdx.x * blockDim.x + threadIdx.x);
-}
-
 struct Wino2Geo {
     int H, W;            // input = output map (pixels)
     int TW;              // tile columns per image = ceil(W / 2)

@@ -1,5 +1,6 @@
-// conv 3x3 (pad 1) as Winograd F(2x2, 3x3) on the bf16 matrix cores, bf16x6 products (fp32 accuracy), for the
-// 32 -> 64 channel block (conv2): 16 products per 2x2 output tile and channel pair instead of 36, and the 2x2
+// conv 3x3 (pad 1) as Winograd F(2x2, 3x3) on the bf16 matrix cores, bf16x6 products (fp32 accuracy), for layers with 64
+// OUTPUT channels -- the 32 -> 64 block (conv2 forward) and, on the transposed / flipped taps, the 128 -> 64 data gradient of
+// conv3 (CIN = 128: eight 16-channel chunks per block, nothing else changes): 16 products per 2x2 output tile and channel pair instead of 36, and the 2x2
 // output tile IS the max-pool window, so BN + ReLU + pool are a maximum over four accumulators.
 //
 //   Y = A^T [ (G g G^T) . (B^T d B) ] A        d: 4x4 input patch, g: 3x3 taps, Y: 2x2 outputs, "." elementwise,
@@ -55,16 +56,48 @@ static __global__ void prep_conv_w_wino_bf16x3_kernel(const float* __restrict__ 
     prep_conv_w_wino_bf16x3_elem(w, wpb, cin, cout, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+// U = G g G^T of the DATA-GRADIENT convolution (channel roles swapped, taps flipped: cf. prep_conv_wT_bf16x3_elem) as
+// bf16x3 planes wpb[plane][(co_f / 16) * 16 + f][ci_f][co_f % 16]; "output" channels = forward INPUT channels
+__device__ __forceinline__ void prep_conv_wT_wino_bf16x3_elem(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin_f, int cout_f, int idx) {
+    const int total = cout_f * 16 * cin_f;
+    if (idx >= total) return;
+    const int e = idx & 15, cop = (idx >> 4) % cin_f, g = (idx >> 4) / cin_f;
+    const int co_f = (g / 16) * 16 + e, f = g % 16, i = f >> 2, j = f & 3;
+    const float* gk = w + ((size_t)co_f * cin_f + cop) * 9;
+    const float Gm[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+    float u = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float t = 0.0f;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) t = fmaf(gk[8 - (k * 3 + l)], Gm[j][l], t);
+        u = fmaf(Gm[i][k], t, u);
+    }
+    if (j == 3) u = -u;
+    unsigned short h, m, l;
+    split3(u, h, m, l);
+    wpb[idx] = h;
+    wpb[(size_t)total + idx] = m;
+    wpb[2 * (size_t)total + idx] = l;
+}
+static __global__ void prep_conv_wT_wino_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin_f, int cout_f) {
+    prep_conv_wT_wino_bf16x3_elem(w, wpb, cin_f, cout_f, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
 // grid (ceil(ceil(W / 2) / 2), ceil(H / 32), B): one block of 16 x 2 tiles per workgroup
 // KNOCK (devtools/kernel_ab/bench_conv.hip timing experiments, results invalid; 0 in the product): bit 0 = no patch loads, bit 1 = no
 // transform / split / LDS writes, bit 2 = no MFMAs, bit 3 = no output stores, bit 4 = weight fragments loaded once per workgroup
-template <int CIN, int COUT, int OUT_MODE, int MINB = 3, int XCD_REMAP = 1, int KNOCK = 0>
+// TCB: tile columns of a block (2: 16 x 2 tiles for the 32-row maps of conv2; 4: 8 x 4 tiles for 16-row maps, where a 16-row
+// block would be half empty); grid (ceil(ceil(W / 2) / TCB), ceil(H / (64 / TCB)), B)
+template <int CIN, int COUT, int OUT_MODE, int MINB = 3, int XCD_REMAP = 1, int KNOCK = 0, int TCB = 2>
 __global__ __launch_bounds__(256, MINB) void conv3x3_wino_bf16x6_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpb, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp, float2* __restrict__ stats) {
     constexpr int NCH = CIN / 16, G = NCH * 16;
     constexpr int PLB = 16 * 1024, FB = 1024;                // bytes per plane / per frequency block
     static_assert(COUT == 64 && CIN % 16 == 0, "two 32-channel slices x two frequency halves = four waves");
+    static_assert(TCB == 2 || TCB == 4, "block shape");
+    constexpr int TCS = TCB == 2 ? 1 : 2, TRB = 32 / TCB;       // tile of the block: column = t & (TCB - 1), row = t >> TCS
     extern __shared__ __attribute__((aligned(16))) unsigned char wl[];
     // Workgroups are dealt to the 8 XCDs round robin (linear id % 8) and each XCD has its own L2: renumber them so that the
     // blocks of one utterance (which share two halo columns with their neighbours) run on ONE XCD, one after the other
@@ -76,7 +109,7 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_wino_bf16x6_kernel(
             bxi = v % nx; bzi = v / nx;
         }
     }
-    const int b = bzi, tx0 = 2 * bxi, ty0 = 16 * blockIdx.y;                     // first tile column / row of the block
+    const int b = bzi, tx0 = TCB * bxi, ty0 = TRB * blockIdx.y;                  // first tile column / row of the block
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wn = wv & 1, wf = wv >> 1;                     // channel slice, frequency half (== staging half: tid >> 7)
     const int m = lane & 31, h = lane >> 5;
@@ -84,8 +117,8 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_wino_bf16x6_kernel(
     // staging role: tile sm = (row sm >> 1, column sm & 1) of the block, channels 4 part .. 4 part + 3 of the chunk.  A wave
     // takes ONE 8-channel half (part >> 1) of all 32 tiles: its ds_write_b64 covers 512 contiguous bytes
     const int part = (tid & 1) + 2 * ((tid >> 6) & 1), sm = (tid >> 1) & 31;
-    const int gy0 = 2 * (ty0 + (sm >> 1)) - 1 + wf;          // first of the three patch rows this half needs (rows wf .. wf + 2)
-    const int gx0 = 2 * (tx0 + (sm & 1)) - 1;
+    const int gy0 = 2 * (ty0 + (sm >> TCS)) - 1 + wf;        // first of the three patch rows this half needs (rows wf .. wf + 2)
+    const int gx0 = 2 * (tx0 + (sm & (TCB - 1))) - 1;
     // patch addresses as 32-bit element offsets row_off[rr] + col_off[j] from one base (clamped into the image: every
     // load is unconditional and in range, padding is a select afterwards -- a bounds branch per load had the compiler
     // spill twelve 64-bit addresses and wait for each reload, one load in flight at a time: 279 us instead of 130)
@@ -239,7 +272,7 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_wino_bf16x6_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int tm = (r & 3) + 8 * (r >> 2) + 4 * h;   // tile of accumulator row r
-            const int ty = ty0 + (tm >> 1), tx = tx0 + (tm & 1);
+            const int ty = ty0 + (tm >> TCS), tx = tx0 + (tm & (TCB - 1));
             if (OUT_MODE == 2) {
 #pragma unroll
                 for (int ya = 0; ya < 2; ++ya)

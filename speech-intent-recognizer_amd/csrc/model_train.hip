@@ -113,7 +113,8 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     n[TB_SLAB] = slab + (size_t)WGR_PARTS * 9 * 128 * 64;       // + the partial sums of the two-pass wgrad reduce
     n[TB_XS] = (B * S * 1024 * 3 + 1) / 2;                       // ushort count / 2 (sizes are in floats)
     n[TB_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512 + 1) / 2;
-    n[TB_WCB] = ((size_t)(3 * 32 * 16 * 64 + 3 * 32 * 9 * 64) + (size_t)2 * 3 * 64 * 9 * 128 + 1) / 2;   // conv2 forward in Winograd form (16 frequencies)
+    // conv2 forward and the conv3 data gradient in Winograd form (16 frequencies), conv3 forward and the conv2 data gradient direct (9 taps)
+    n[TB_WCB] = ((size_t)(3 * 32 * 16 * 64 + 3 * 32 * 9 * 64) + (size_t)3 * 64 * 9 * 128 + (size_t)3 * 128 * 16 * 64 + 1) / 2;
     n[TB_GXB] = 64;
     n[TB_GFL] = 64;
     n[TB_C1M] = 2 * C1_NMOM;
@@ -226,7 +227,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
         add(4, w->conv_w[1], p.wcb2, 32, 64, (32 * 16 * 64 + 255) / 256);       // conv2 forward: Winograd frequencies
         add(1, w->conv_w[2], p.wcb3, 64, 128, (64 * 9 * 128 + 255) / 256);
         add(2, w->conv_w[1], p.wcb2t, 32, 64, (32 * 9 * 64 + 255) / 256);
-        add(2, w->conv_w[2], p.wcb3t, 64, 128, (64 * 9 * 128 + 255) / 256);
+        add(5, w->conv_w[2], p.wcb3t, 64, 128, (128 * 16 * 64 + 255) / 256);   // conv3 data gradient: Winograd frequencies of the flipped taps
         for (int dir = 0; dir < 2; ++dir) {
             add(0, w->gru_w_ih[dir], p.wsl0 + (size_t)dir * 3 * 768 * 1024, 1024, 768, 384);
             add(0, w->gru_w_ih[2 + dir], p.wsl1 + (size_t)dir * 3 * 768 * 512, 512, 768, 192);
@@ -492,9 +493,10 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                                g->conv_w[2]);
         }
         {
-            // data gradient = the forward kernel on the flipped / transposed prepared weights p.wcb3t (train_prep_kernel of the forward)
+            // data gradient = a 128 -> 64 convolution with the flipped / transposed taps: the Winograd kernel (16 of 36 products), blocks
+            // of 8 x 4 tiles for the 16-row map, raw output (train_prep_kernel of the forward built p.wcb3t)
             SirProfScope prof(h, SIR_K_B_DGRAD3, st);
-            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<128, 64, 2, 4, 2, 0, 2, 1, 1>), dim3(d.c3gx, 1, B), dim3(256), conv_ns_lds_bytes(2, 4, 2), st,
+            hipLaunchKernelGGL((conv3x3_wino_bf16x6_kernel<128, 64, 2, 3, 1, 0, 4>), dim3(((d.wp2 + 1) / 2 + 3) / 4, 1, B), dim3(256), WINO_LDS_BYTES, st,
                                (const float*)p.dz3, (const unsigned short*)p.wcb3t, (const float*)nullptr, (const float*)nullptr, p.da2, 16, d.wp2,
                                8, d.wp3, (float2*)nullptr);
         }

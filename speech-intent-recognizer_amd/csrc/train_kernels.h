@@ -511,7 +511,8 @@ __device__ __forceinline__ void prep_whh_bwd_elem(const float* __restrict__ w, f
 
 // Every per-step re-layout of the weights (they change with each optimizer step) in ONE launch: a dozen ~5 us launches
 // otherwise.  kind 0: split3_rows (a = ld_in = K, b = rows), 1: prep_conv_w_bf16x3 (a = cin, b = cout),
-// 2: prep_conv_wT_bf16x3 (a = cin_f, b = cout_f), 3: prep_whh_bwd, 4: prep_conv_w_wino_bf16x3 (a = cin, b = cout).  Job j owns blocks [block0[j], block0[j+1]).
+// 2: prep_conv_wT_bf16x3 (a = cin_f, b = cout_f), 3: prep_whh_bwd, 4: prep_conv_w_wino_bf16x3 (a = cin, b = cout),
+// 5: prep_conv_wT_wino_bf16x3 (a = cin_f, b = cout_f).  Job j owns blocks [block0[j], block0[j+1]).
 constexpr int PREP_MAX_JOBS = 12;
 struct PrepJobs {
     const float* src[PREP_MAX_JOBS];
@@ -531,6 +532,7 @@ static __global__ __launch_bounds__(256) void train_prep_kernel(PrepJobs jobs) {
         case 1: prep_conv_w_bf16x3_elem(src, (unsigned short*)jobs.dst[j], jobs.a[j], jobs.b[j], idx); break;
         case 2: prep_conv_wT_bf16x3_elem(src, (unsigned short*)jobs.dst[j], jobs.a[j], jobs.b[j], idx); break;
         case 4: prep_conv_w_wino_bf16x3_elem(src, (unsigned short*)jobs.dst[j], jobs.a[j], jobs.b[j], idx); break;
+        case 5: prep_conv_wT_wino_bf16x3_elem(src, (unsigned short*)jobs.dst[j], jobs.a[j], jobs.b[j], idx); break;
         default: prep_whh_bwd_elem(src, (float*)jobs.dst[j], idx); break;
     }
 }
