@@ -13,7 +13,7 @@
 #include "../../speech-intent-recognizer_amd/csrc/bf16x6_kernels.h"
 #include "legacy_kernels.h"
 #include "../../speech-intent-recognizer_amd/csrc/conv_wino_bf16x6_kernel.h"
-#include "conv_wino2_bf16x6_kernel.h"
+#include "../../speech-intent-recognizer_amd/csrc/conv_wino2_bf16x6_kernel.h"
 
 #define CK_(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -275,13 +275,13 @@ static void run_wino2(const char* name, int B, int H, int W, int reps = 60) {
     float *dx, *dw, *ds, *dt, *o1, *o2;
     unsigned short *wpb, *wpw, *pl1 = nullptr, *pl2 = nullptr;
     Wino2Geo geo;
-    if (!wino2_geo(B, H, W, &geo)) { printf("%s: unsupported shape\n", name); return; }
+    if (!wino2_geo(B, H, W, CIN > COUT ? CIN : COUT, &geo)) { printf("%s: unsupported shape\n", name); return; }
     const dim3 gd((W + 4 * PC - 1) / (4 * PC), (H + 8 * PR - 1) / (8 * PR), B);
     float2 *st1 = nullptr, *st2 = nullptr;
     CK_(hipMalloc(&dx, nx * 4)); CK_(hipMalloc(&dw, nw * 4)); CK_(hipMalloc(&ds, COUT * 4)); CK_(hipMalloc(&dt, COUT * 4));
     CK_(hipMalloc(&o1, nout * 4)); CK_(hipMalloc(&o2, nout * 4)); CK_(hipMalloc(&wpb, nw * 6)); CK_(hipMalloc(&wpw, (size_t)COUT * CIN * 16 * 6));
     if (MODE == 1) { CK_(hipMalloc(&pl1, nout * 6)); CK_(hipMalloc(&pl2, nout * 6)); CK_(hipMemset(pl1, 0, nout * 6)); CK_(hipMemset(pl2, 0, nout * 6)); }
-    if (MODE == 2) { CK_(hipMalloc(&st1, (size_t)gd.x * gd.y * B * COUT * 8)); CK_(hipMalloc(&st2, (size_t)geo.NS * COUT * 8)); }
+    if (MODE == 2) { CK_(hipMalloc(&st1, (size_t)gd.x * gd.y * B * COUT * 8)); CK_(hipMalloc(&st2, (size_t)geo.NS * 4 * COUT * 8)); }
     CK_(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
     CK_(hipMemcpy(ds, hs.data(), COUT * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(dt, ht.data(), COUT * 4, hipMemcpyHostToDevice));
     hipStream_t st; CK_(hipStreamCreate(&st));
@@ -297,11 +297,12 @@ static void run_wino2(const char* name, int B, int H, int W, int reps = 60) {
     constexpr int DM = MODE == 3 ? 2 : MODE;              // the direct kernel's raw mode
     constexpr int DB = (PR * PC <= 8 && MINB == 2) ? 1 : 0;
     bool attr = false;
+    float* dzero; CK_(hipMalloc(&dzero, 4096)); CK_(hipMemset(dzero, 0, 4096));       // zero page of the DMA (>= CIN + 4 floats)
     auto direct = [&](const float* in) {
         hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, PR, PC, DM, 0, MINB, 1, DB>), gd, dim3(256), conv_ns_lds_bytes(PR, PC, DB ? 2 : 1), st, in,
                            (const unsigned short*)wpb, (const float*)ds, (const float*)dt, o1, H, W, Hp, Wp, MODE == 1 ? (float2*)pl1 : st1); };
     auto wino2 = [&](const float* in) {
-        CK_((launch_conv_wino2<CIN, COUT, MODE>(st, &attr, in, wpw, ds, dt, o2, B, H, W, MODE == 1 ? (float2*)pl2 : st2))); };
+        CK_((launch_conv_wino2<CIN, COUT, MODE>(st, &attr, in, wpw, ds, dt, o2, B, H, W, MODE == 1 ? (float2*)pl2 : st2, dzero))); };
     direct(dx); wino2(dx);
     CK_(hipStreamSynchronize(st));
     {
@@ -329,7 +330,7 @@ static void run_wino2(const char* name, int B, int H, int W, int reps = 60) {
             printf("  bf16x3 planes (hi + mid + lo): max difference %.3e\n", dp);
         }
         if (MODE == 2) {
-            const size_t n1 = (size_t)gd.x * gd.y * B, n2 = geo.NS;
+            const size_t n1 = (size_t)gd.x * gd.y * B, n2 = (size_t)geo.NS * 4;
             std::vector<float2> s1(n1 * COUT), s2(n2 * COUT);
             CK_(hipMemcpy(s1.data(), st1, s1.size() * 8, hipMemcpyDeviceToHost)); CK_(hipMemcpy(s2.data(), st2, s2.size() * 8, hipMemcpyDeviceToHost));
             double worst = 0;
@@ -354,8 +355,20 @@ static void run_wino2(const char* name, int B, int H, int W, int reps = 60) {
         // phase stamps of workgroup 0, second task (cycles relative to the first stamp): group A | group B
         bool attr2 = false;
         for (int rep = 0; rep < 3; ++rep)
-            CK_((launch_conv_wino2<CIN, COUT, MODE, 1>(st, &attr2, dx, wpw, ds, dt, o2, B, H, W, MODE == 1 ? (float2*)pl2 : st2)));
+            CK_((launch_conv_wino2<CIN, COUT, MODE, 1>(st, &attr2, dx, wpw, ds, dt, o2, B, H, W, MODE == 1 ? (float2*)pl2 : st2, dzero)));
         CK_(hipStreamSynchronize(st));
+        {
+            auto ko = [&](auto kc) {
+                bool at = false;
+                return time_us(st, reps, [&] { CK_((launch_conv_wino2<CIN, COUT, MODE, decltype(kc)::value>(st, &at, dx, wpw, ds, dt, o2, B, H, W, MODE == 1 ? (float2*)pl2 : st2, dzero))); });
+            };
+            using std::integral_constant;
+            printf("  knock-outs (timing only, one cached input): full %.1f, no DMA %.1f, no transform %.1f, no MFMA %.1f, no epilogue %.1f, no transform+MFMA %.1f, only barriers+epilogue %.1f us\n",
+                   ko(integral_constant<int, 32>{}), ko(integral_constant<int, 2>{}), ko(integral_constant<int, 4>{}), ko(integral_constant<int, 8>{}), ko(integral_constant<int, 16>{}),
+                   ko(integral_constant<int, 12>{}), ko(integral_constant<int, 14>{}));
+            printf("  more: weights loaded once %.1f, weights once + only barriers/epilogue %.1f, weights once + no epilogue %.1f us\n",
+                   ko(integral_constant<int, 64>{}), ko(integral_constant<int, 78>{}), ko(integral_constant<int, 80>{}));
+        }
         long long hs_[2][32];
         CK_(hipMemcpyFromSymbol(hs_, HIP_SYMBOL(w2_dbg_stamps), sizeof(hs_)));
         for (int g = 0; g < 2; ++g) {

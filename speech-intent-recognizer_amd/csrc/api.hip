@@ -55,6 +55,8 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     h->cluster_always = getenv("SIR_CLUSTER_EVENTS") && atoi(getenv("SIR_CLUSTER_EVENTS")) == 1;   // A/B switch: chained mode throughout
     if (h->cluster_always) h->cluster_multi = true;
     h->attr_gemm_v3 = h->attr_gru_quad = h->attr_gru_bwd = h->attr_tn = h->attr_wgrad = false;
+    for (auto& a : h->attr_wino2) a = false;
+    h->zero_page = nullptr; h->num_cus = 256;
     for (auto& x : h->xbufs) { x.st = nullptr; x.p = nullptr; x.kind = 0; x.cap = 0; x.bytes = 0; x.epoch = 0; x.used = 0; }
     h->xbuf_clock = 0;
     h->cfg = *cfg;
@@ -127,6 +129,11 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     if (rc == SIR_OK) rc = upload(&h->melw, melw);
     if (rc == SIR_OK) rc = upload(&h->mel_desc, desc);
     if (rc == SIR_OK) rc = upload(&h->status, std::vector<unsigned int>(64, 0u));
+    if (rc == SIR_OK) rc = upload(&h->zero_page, std::vector<float>(1024, 0.0f));
+    if (rc == SIR_OK) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->num_cus = cus;
+    }
     if (rc == SIR_OK) rc = sir_check_hip(hipEventCreateWithFlags(&h->cluster_done, hipEventDisableTiming), "hipEventCreate");
     if (rc != SIR_OK) { sir_destroy(h); return rc; }
     *out = h;
@@ -139,6 +146,7 @@ extern "C" int sir_destroy(sir_handle* h) {
     (void)hipFree(h->melw); (void)hipFree(h->mel_desc); (void)hipFree(h->status);
     if (h->cluster_done) (void)hipEventDestroy(h->cluster_done);
     for (auto& x : h->xbufs) (void)hipFree(x.p);
+    (void)hipFree(h->zero_page);
     for (auto& t : h->resample_tables) { (void)hipFree(t.taps); (void)hipFree(t.first); }
     for (auto& r : h->prof_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : h->prof_free) (void)hipEventDestroy(e);

@@ -2,6 +2,7 @@
 // as a fixed sequence of hand-written kernels on one stream.  See model_kernels.h for the kernels.
 #include "bf16x6_kernels.h"
 #include "conv_wino_bf16x6_kernel.h"
+#include "conv_wino2_bf16x6_kernel.h"
 
 namespace {
 
@@ -50,7 +51,7 @@ void ws_sizes(const Dims& d, size_t* bytes) {
     bytes[WS_WHT] = (size_t)4 * 768 * 256 * 6;                  // W_hh as the resident bf16x3 MFMA fragments of the recurrence kernel
     bytes[WS_XS] = B * d.S * 1024 * 3 * 2;
     bytes[WS_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512) * 2;
-    bytes[WS_WCB] = ((size_t)3 * 32 * 16 * 64 + (size_t)3 * 64 * 9 * 128) * 2;     // conv2: 16 Winograd frequencies per (cout, cin); conv3: 9 taps
+    bytes[WS_WCB] = ((size_t)3 * 32 * 16 * 64 + (size_t)3 * 64 * 16 * 128 + (size_t)3 * 64 * 9 * 128) * 2;   // conv2, conv3: 16 Winograd frequencies per (cout, cin); conv3 again with 9 taps for the direct kernel (shapes the Winograd kernel does not cover)
     bytes[WS_GXB] = 0;
     bytes[WS_GFL] = 0;
 }
@@ -119,7 +120,8 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     unsigned short* wsl0 = (unsigned short*)(ws + off[WS_WS]);
     unsigned short* wsl1 = wsl0 + (size_t)2 * 3 * 768 * 1024;
     unsigned short* wcb2 = (unsigned short*)(ws + off[WS_WCB]);
-    unsigned short* wcb3 = wcb2 + (size_t)3 * 32 * 16 * 64;
+    unsigned short* wcb3 = wcb2 + (size_t)3 * 32 * 16 * 64;       // Winograd form
+    unsigned short* wcb3d = wcb3 + (size_t)3 * 64 * 16 * 128;     // direct form (fallback)
     const int B = d.B, S = d.S;
 
     // ---- weight preparation -------------------------------------------------------------
@@ -138,7 +140,8 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
                                bns + bn_o[i], bnt + bn_o[i], bn_c[i]);
         for (int i = 0; i < 4; ++i) sir_prep_whh_quad(st, w->gru_w_hh[i], (unsigned char*)wht + (size_t)i * 768 * 256 * 6);
         hipLaunchKernelGGL(prep_conv_w_wino_bf16x3_kernel, dim3((32 * 16 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], wcb2, 32, 64);
-        hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], wcb3, 64, 128);
+        hipLaunchKernelGGL(prep_conv_w_wino_bf16x3_kernel, dim3((64 * 16 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], wcb3, 64, 128);
+        hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], wcb3d, 64, 128);
         for (int dir = 0; dir < 2; ++dir) {
             hipLaunchKernelGGL(split3_kernel, dim3(384), dim3(256), 0, st, w->gru_w_ih[dir], 1024, wsl0 + (size_t)dir * 3 * 768 * 1024, (size_t)768, 1024);
             hipLaunchKernelGGL(split3_kernel, dim3(192), dim3(256), 0, st, w->gru_w_ih[2 + dir], 512, wsl1 + (size_t)dir * 3 * 768 * 512, (size_t)768, 512);
@@ -154,18 +157,29 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
         hipLaunchKernelGGL(conv1_mfma_bn_relu_pool_kernel, dim3((d.wp1 + C1_PCOLS - 1) / C1_PCOLS, 1, B), dim3(256), 0, st, feats,
                            w->conv_w[0], bns, bnt, a1, 64, d.T, 32, d.wp1);
     }
+    // conv2 / conv3 as Winograd F(2x2, 3x3) -- the 2x2 output tile is the pooling window -- on the producer / consumer kernel
+    // (conv_wino2_bf16x6_kernel.h); shapes it does not cover (batch x map beyond 32-bit offsets) keep the first-generation kernels
+    Wino2Geo geo2, geo3;
+    const bool w2ok = wino2_geo(B, 32, d.wp1, 64, &geo2) && wino2_geo(B, 16, d.wp2, 128, &geo3);
     {
         SirProfScope prof(h, SIR_K_CONV2, st);
-        // conv2 as Winograd F(2x2, 3x3): the 2x2 output tile is the pooling window (conv_wino_bf16x6_kernel.h)
-        hipLaunchKernelGGL((conv3x3_wino_bf16x6_kernel<32, 64, 0>), dim3(((d.wp1 + 1) / 2 + 1) / 2, 1, B), dim3(256), WINO_LDS_BYTES, st,
-                           a1, (const unsigned short*)wcb2, bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
+        if (w2ok)
+            SIR_HIP_TRY((launch_conv_wino2<32, 64, 0>(st, &h->attr_wino2[0], a1, (const unsigned short*)wcb2, bns + 32, bnt + 32, a2, B, 32, d.wp1,
+                                                    (float2*)nullptr, h->zero_page, h->num_cus)));
+        else
+            hipLaunchKernelGGL((conv3x3_wino_bf16x6_kernel<32, 64, 0>), dim3(((d.wp1 + 1) / 2 + 1) / 2, 1, B), dim3(256), WINO_LDS_BYTES, st,
+                               a1, (const unsigned short*)wcb2, bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
     }
     {
         // conv3 stores straight into the GRU input layout [B][S][c*8+h] (models.py:55-57) and writes the bf16x3 planes of
         // the first input projection's A operand beside it
         SirProfScope prof(h, SIR_K_CONV3, st);
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 1, 0, 2, 1, 1>), dim3((d.wp2 + 7) / 8, 1, B), dim3(256), conv_ns_lds_bytes(2, 2, 2), st,
-                           a2, (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)xs);
+        if (w2ok)
+            SIR_HIP_TRY((launch_conv_wino2<64, 128, 1>(st, &h->attr_wino2[1], a2, (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, B, 16, d.wp2,
+                                                     (float2*)xs, h->zero_page, h->num_cus)));
+        else
+            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 1, 0, 2, 1, 1>), dim3((d.wp2 + 7) / 8, 1, B), dim3(256), conv_ns_lds_bytes(2, 2, 2), st,
+                               a2, (const unsigned short*)wcb3d, bns + 96, bnt + 96, x0, 16, d.wp2, 8, d.wp3, (float2*)xs);
     }
     SIR_KCHECK();
 

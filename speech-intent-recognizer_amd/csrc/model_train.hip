@@ -4,6 +4,7 @@
 // train_epoch (scripts/train.py:90-107: forward, criterion, loss.backward(), optimizer.step()).
 #include "bf16x6_kernels.h"
 #include "train_kernels.h"
+#include "conv_wino2_bf16x6_kernel.h"
 #include "wgrad_bf16x6_kernel.h"
 #include "gemm_tn_bf16x6_kernel.h"
 
@@ -83,7 +84,10 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     n[TB_BN] = 4 * 224;
     n[TB_BNB] = 2 * 224;
     size_t st = (size_t)d.c1gx * d.c1gy * B * 32;                       // conv1 partials (float2)
-    const size_t s2 = (size_t)d.c2wx * B * 64, s3 = (size_t)d.c3fx * B * 128;
+    // per-(task, tile column) statistics of the producer / consumer Winograd kernel (or per-workgroup ones of the fallback kernels)
+    size_t s2 = (size_t)d.c2wx * B * 64, s3 = (size_t)d.c3fx * B * 128;
+    if (wino2_stat_blocks(d.B, 32, d.wp1) * 64 > s2) s2 = wino2_stat_blocks(d.B, 32, d.wp1) * 64;
+    if (wino2_stat_blocks(d.B, 16, d.wp2) * 128 > s3) s3 = wino2_stat_blocks(d.B, 16, d.wp2) * 128;
     if (s2 > st) st = s2;
     if (s3 > st) st = s3;
     const size_t bw = (size_t)(B * 16 * d.wp1 / 64 + 64) * 128;          // bn backward partials, generous
@@ -114,7 +118,7 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     n[TB_XS] = (B * S * 1024 * 3 + 1) / 2;                       // ushort count / 2 (sizes are in floats)
     n[TB_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512 + 1) / 2;
     // conv2 forward and the conv3 data gradient in Winograd form (16 frequencies), conv3 forward and the conv2 data gradient direct (9 taps)
-    n[TB_WCB] = ((size_t)(3 * 32 * 16 * 64 + 3 * 32 * 9 * 64) + (size_t)3 * 64 * 9 * 128 + (size_t)3 * 128 * 16 * 64 + 1) / 2;
+    n[TB_WCB] = ((size_t)(3 * 32 * 16 * 64 + 3 * 32 * 9 * 64) + (size_t)3 * 64 * 16 * 128 + (size_t)3 * 128 * 16 * 64 + (size_t)3 * 64 * 9 * 128 + 1) / 2;
     n[TB_GXB] = 64;
     n[TB_GFL] = 64;
     n[TB_C1M] = 2 * C1_NMOM;
@@ -137,7 +141,7 @@ struct TPtrs {
     float *a1, *z2, *a2, *z3, *x0, *gi, *g0, *g1, *y0, *y0d, *y1, *ctx, *bn, *bnb, *wp2, *wp3, *wht, *wr4, *wp2t, *wp3t;
     float *dy1, *dy0, *dgi, *dgh, *dx0, *dz3, *da2, *dz2, *da1, *small, *slab;
     float2* stats;
-    unsigned short *xs, *wsl0, *wsl1, *wcb2, *wcb3, *wcb2t, *wcb3t;
+    unsigned short *xs, *wsl0, *wsl1, *wcb2, *wcb3, *wcb2t, *wcb3t, *wcb3d;
     unsigned int* gfl;
     double* c1m;
 };
@@ -159,7 +163,8 @@ TPtrs carve(void* ws, const size_t* off) {
     p.xs = (unsigned short*)(b + off[TB_XS]);
     p.wsl0 = (unsigned short*)(b + off[TB_WS]); p.wsl1 = p.wsl0 + (size_t)2 * 3 * 768 * 1024;
     p.wcb2 = (unsigned short*)(b + off[TB_WCB]); p.wcb3 = p.wcb2 + (size_t)3 * 32 * 16 * 64;
-    p.wcb2t = p.wcb3 + (size_t)3 * 64 * 9 * 128; p.wcb3t = p.wcb2t + (size_t)3 * 32 * 9 * 64;
+    p.wcb2t = p.wcb3 + (size_t)3 * 64 * 16 * 128; p.wcb3t = p.wcb2t + (size_t)3 * 32 * 9 * 64;
+    p.wcb3d = p.wcb3t + (size_t)3 * 128 * 16 * 64;           // conv3 forward with 9 taps: only for shapes the Winograd kernel does not cover
     p.gfl = (unsigned int*)(b + off[TB_GFL]);
     p.c1m = (double*)(b + off[TB_C1M]);
     return p;
@@ -216,6 +221,10 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     const int B = d.B, S = d.S, T = d.T;
     float *scale = p.bn, *shift = p.bn + 224, *smean = p.bn + 448, *sinv = p.bn + 672;
 
+    // conv2 / conv3 forward and the conv3 data gradient run on the producer / consumer Winograd kernel (conv_wino2_bf16x6_kernel.h);
+    // shapes it does not cover keep the first-generation / direct kernels
+    Wino2Geo geo2, geo3;
+    const bool w2ok = wino2_geo(B, 32, d.wp1, 64, &geo2) && wino2_geo(B, 16, d.wp2, 128, &geo3);
     {   // all weight re-layouts of this step, the backward's included (the weights do not change before it runs)
         SirProfScope prof(h, SIR_K_T_PREP, st);
         PrepJobs pj{};
@@ -225,7 +234,8 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
             blocks += nblk; ++nj;
         };
         add(4, w->conv_w[1], p.wcb2, 32, 64, (32 * 16 * 64 + 255) / 256);       // conv2 forward: Winograd frequencies
-        add(1, w->conv_w[2], p.wcb3, 64, 128, (64 * 9 * 128 + 255) / 256);
+        add(4, w->conv_w[2], p.wcb3, 64, 128, (64 * 16 * 128 + 255) / 256);     // conv3 forward: Winograd frequencies
+        if (!w2ok) add(1, w->conv_w[2], p.wcb3d, 64, 128, (64 * 9 * 128 + 255) / 256);
         add(2, w->conv_w[1], p.wcb2t, 32, 64, (32 * 9 * 64 + 255) / 256);
         add(5, w->conv_w[2], p.wcb3t, 64, 128, (128 * 16 * 64 + 255) / 256);   // conv3 data gradient: Winograd frequencies of the flipped taps
         for (int dir = 0; dir < 2; ++dir) {
@@ -258,11 +268,15 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     // conv2 block: raw conv + partial statistics on MFMA, finalize, BN+ReLU+pool
     {
         { SirProfScope prof(h, SIR_K_T_CONV2, st);
-        hipLaunchKernelGGL((conv3x3_wino_bf16x6_kernel<32, 64, 2>), dim3(d.c2wx, 1, B), dim3(256), WINO_LDS_BYTES, st, (const float*)p.a1,
-                           (const unsigned short*)p.wcb2, (const float*)nullptr, (const float*)nullptr, p.z2, 32, d.wp1, 16, d.wp2, p.stats);
+        if (w2ok)
+            SIR_HIP_TRY((launch_conv_wino2<32, 64, 2>(st, &h->attr_wino2[2], (const float*)p.a1, (const unsigned short*)p.wcb2, (const float*)nullptr,
+                                                    (const float*)nullptr, p.z2, B, 32, d.wp1, p.stats, h->zero_page, h->num_cus)));
+        else
+            hipLaunchKernelGGL((conv3x3_wino_bf16x6_kernel<32, 64, 2>), dim3(d.c2wx, 1, B), dim3(256), WINO_LDS_BYTES, st, (const float*)p.a1,
+                               (const unsigned short*)p.wcb2, (const float*)nullptr, (const float*)nullptr, p.z2, 32, d.wp1, 16, d.wp2, p.stats);
         }
         SirProfScope prof(h, SIR_K_T_BN2, st);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, d.c2wx * B, 64,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, w2ok ? (int)wino2_stat_blocks(B, 32, d.wp1) : d.c2wx * B, 64,
                            (double)B * 32 * d.wp1, w->bn_w[1], w->bn_b[1], bn_running_mean[1], bn_running_var[1], bn_momentum,
                            scale + 32, shift + 32, smean + 32, sinv + 32);
         hipLaunchKernelGGL(bn_relu_pool_kernel<false>, dim3(grid_for((size_t)B * 16 * d.wp2 * 16)), dim3(256), 0, st, p.z2,
@@ -270,11 +284,15 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     }
     {
         { SirProfScope prof(h, SIR_K_T_CONV3, st);
-        hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 2, 0, 2, 1, 1>), dim3(d.c3fx, 1, B), dim3(256), conv_ns_lds_bytes(2, 2, 2), st, (const float*)p.a2,
-                           (const unsigned short*)p.wcb3, (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats);
+        if (w2ok)
+            SIR_HIP_TRY((launch_conv_wino2<64, 128, 2>(st, &h->attr_wino2[3], (const float*)p.a2, (const unsigned short*)p.wcb3, (const float*)nullptr,
+                                                     (const float*)nullptr, p.z3, B, 16, d.wp2, p.stats, h->zero_page, h->num_cus)));
+        else
+            hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 2, 0, 2, 1, 1>), dim3(d.c3fx, 1, B), dim3(256), conv_ns_lds_bytes(2, 2, 2), st, (const float*)p.a2,
+                               (const unsigned short*)p.wcb3d, (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats);
         }
         SirProfScope prof(h, SIR_K_T_BN3, st);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, d.c3fx * B, 128,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, w2ok ? (int)wino2_stat_blocks(B, 16, d.wp2) : d.c3fx * B, 128,
                            (double)B * 16 * d.wp2, w->bn_w[2], w->bn_b[2], bn_running_mean[2], bn_running_var[2], bn_momentum,
                            scale + 96, shift + 96, smean + 96, sinv + 96);
         hipLaunchKernelGGL(bn_relu_pool_kernel<true>, dim3(grid_for((size_t)B * 8 * d.wp3 * 32)), dim3(256), 0, st, p.z3,
@@ -496,9 +514,14 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             // data gradient = a 128 -> 64 convolution with the flipped / transposed taps: the Winograd kernel (16 of 36 products), blocks
             // of 8 x 4 tiles for the 16-row map, raw output (train_prep_kernel of the forward built p.wcb3t)
             SirProfScope prof(h, SIR_K_B_DGRAD3, st);
-            hipLaunchKernelGGL((conv3x3_wino_bf16x6_kernel<128, 64, 2, 3, 1, 0, 4>), dim3(((d.wp2 + 1) / 2 + 3) / 4, 1, B), dim3(256), WINO_LDS_BYTES, st,
-                               (const float*)p.dz3, (const unsigned short*)p.wcb3t, (const float*)nullptr, (const float*)nullptr, p.da2, 16, d.wp2,
-                               8, d.wp3, (float2*)nullptr);
+            Wino2Geo geo3b;
+            if (wino2_geo(B, 16, d.wp2, 128, &geo3b))
+                SIR_HIP_TRY((launch_conv_wino2<128, 64, 3>(st, &h->attr_wino2[4], (const float*)p.dz3, (const unsigned short*)p.wcb3t, (const float*)nullptr,
+                                                         (const float*)nullptr, p.da2, B, 16, d.wp2, (float2*)nullptr, h->zero_page, h->num_cus)));
+            else
+                hipLaunchKernelGGL((conv3x3_wino_bf16x6_kernel<128, 64, 2, 3, 1, 0, 4>), dim3(((d.wp2 + 1) / 2 + 3) / 4, 1, B), dim3(256), WINO_LDS_BYTES, st,
+                                   (const float*)p.dz3, (const unsigned short*)p.wcb3t, (const float*)nullptr, (const float*)nullptr, p.da2, 16, d.wp2,
+                                   8, d.wp3, (float2*)nullptr);
         }
         KCHECK();
     }

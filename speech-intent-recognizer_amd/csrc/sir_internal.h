@@ -73,6 +73,9 @@ struct sir_handle {
     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) latches, per handle = per device (a process-wide static would skip
     // the second device of a process that drives several)
     bool attr_gemm_v3, attr_gru_quad, attr_gru_bwd, attr_tn, attr_wgrad;
+    bool attr_wino2[8];                // conv3x3_wino2_bf16x6_kernel instantiations (model_infer.hip / model_train.hip index them)
+    float* zero_page;                  // 4 KB of zeros: DMA source of the second-generation Winograd kernel's out-of-image pixels
+    int num_cus;                       // persistent kernels launch one workgroup per CU
     // Exchange-granule buffers of the cluster kernels (GRU recurrences).  They are OWNED by the handle (hipMalloc), one per
     // (launch stream, kernel kind): nothing but that kernel ever writes them, so a granule found there is always one of its
     // own from an earlier launch and the launch epoch in its tag tells it apart.  (They used to be carved out of the caller's
