@@ -350,7 +350,10 @@ static void run_wino2(const char* name, int B, int H, int W, int reps = 60) {
         const float t1 = time_us(st, reps, [&] { direct(dxr[rot++ & 3]); });
         const float t2 = time_us(st, reps, [&] { wino2(dxr[rot++ & 3]); });
         const double gf = 2.0 * B * H * W * (double)COUT * CIN * 9 * 1e-9;
-        printf("  rotating inputs: direct %.1f us (%.1f TF)   wino2 %.1f us (%.1f TF algorithmic)\n", t1, gf * 1e3 / t1, t2, gf * 1e3 / t2);
+        bool atp[3] = {false, false, false};
+        const float tp1 = time_us(st, reps, [&] { CK_((launch_conv_wino2<CIN, COUT, MODE, 0, 1>(st, &atp[0], dxr[rot++ & 3], wpw, ds, dt, o2, B, H, W, MODE == 1 ? (float2*)pl2 : st2, dzero))); });
+        const float tp2 = time_us(st, reps, [&] { CK_((launch_conv_wino2<CIN, COUT, MODE, 0, 3>(st, &atp[1], dxr[rot++ & 3], wpw, ds, dt, o2, B, H, W, MODE == 1 ? (float2*)pl2 : st2, dzero))); });
+        printf("  rotating inputs: direct %.1f us (%.1f TF)   wino2 %.1f us (%.1f TF algorithmic); producers at s_setprio 1: %.1f, 3: %.1f us\n", t1, gf * 1e3 / t1, t2, gf * 1e3 / t2, tp1, tp2);
         for (int k = 0; k < 4; ++k) (void)hipFree(dxr[k]);
         // phase stamps of workgroup 0, second task (cycles relative to the first stamp): group A | group B
         bool attr2 = false;

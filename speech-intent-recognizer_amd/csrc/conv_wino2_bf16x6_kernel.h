@@ -99,7 +99,7 @@ __device__ long long w2_dbg_stamps[2][32];
 // Fourth structure: 12 waves per workgroup -- 4 producers (raw patches by LDS-DMA three chunks deep, B^T d B, bf16x3, V[step & 1])
 // and 8 consumers (wave (i, n): transform row i, channel slice n: 4 accumulators, weights of its 4 frequencies one chunk ahead),
 // one barrier per chunk; a task's row transform goes through the V buffer its last chunk just left (two extra barriers per task).
-template <int CIN, int COUT, int OUT_MODE, int DBG = 0>
+template <int CIN, int COUT, int OUT_MODE, int DBG = 0, int PRIO = 3>
 __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpb, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, Wino2Geo geo, float2* __restrict__ stats, const float* __restrict__ zeros) {
@@ -109,7 +109,9 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
     unsigned char* const vbuf = w2s;                                    // [2][3 planes][16 f][1 KB]
     unsigned char* const rawbuf = w2s + 2 * W2_V_BYTES;                 // [3][13 KB]
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // the wave index as a SCALAR (readfirstlane): everything derived from it -- roles, rows, channel slices, weight addresses -- then
+    // lives in SGPRs; derived from threadIdx alone hipcc keeps it all in vector registers (+40 VGPRs in the consumer loop: spills)
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wv < 4;
     const int H = geo.H, W = geo.W, TW = geo.TW, NG = geo.NG, RBN = geo.RBN;
     const int ntask_s = (geo.NS - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // spatial tasks of this workgroup
@@ -131,6 +133,8 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
 
     if (producer) {
         // ================= producers ==============================================================================================
+        // (their VALU stream competes with two MFMA-issuing consumer waves for the SIMD's issue port: priority to the producer)
+        if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
         const int wg = wv;
         // wave wg = (row pair tR of the transform, 8-channel half tH); lane = (tile tm, 4-channel group tP1)
         const int tR = wg >> 1, tH = wg & 1, tm = lane >> 1, tP1 = lane & 1;
@@ -250,11 +254,14 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
     // ================= consumers ==================================================================================================
     // wave (n = cw & 1, i = cw >> 1): channel slice 32 n.., transform row i (frequencies 4 i .. 4 i + 3, 4 accumulators)
     const int cw = wv - 4, mn = cw & 1, mi = cw >> 1, m = lane & 31, h = lane >> 5;
-    const uint4* const wp4 = reinterpret_cast<const uint4*>(wpb) + (size_t)(mn * 32 + m) * 2 + h;     // + (p * G + g) * COUT * 2 + ch * 128
+    // U fragment address = uniform part (plane, frequency, channel block, slice: scalar registers) + this lane's 32-bit byte offset
+    const unsigned wlane = (unsigned)((m * 2 + h) * 16);
+    const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(wpb) + (size_t)mn * 1024;
     uint4 wq[4][3];                                                     // U fragments of the wave's four frequencies, one chunk ahead
     auto load_w = [&](int gidx, int chh, uint4 (&q)[3]) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) q[p] = wp4[(p * G + gidx) * (COUT * 2) + chh * 128];
+        for (int p = 0; p < 3; ++p)
+            q[p] = *reinterpret_cast<const uint4*>(wbase + ((size_t)(p * G + gidx) * (COUT * 2) + (size_t)chh * 128) * 16 + wlane);
     };
     int g0, ty0, ch, s_idx;
     task_geo(0, g0, ty0, ch, s_idx);
@@ -267,19 +274,26 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
     w2_barrier();                                                    // (pairs with the producers' "raw chunks 0 and 1 have landed")
 
+    stamp();
+    stamp();
+    w2_barrier();                                                       // step 0: the producers transform the first chunk
+    // step s = lt * NCH + c + 1 multiplies chunk sc = s - 1.  Nested loops (tasks, chunks) rather than one step loop with a runtime
+    // "task ends here" flag: with the epilogue inside the step loop hipcc kept its working set alive through the matrix steps and
+    // spilled the weight ring into them (376-480 B of scratch per lane for 64 and 128 input channels)
 #pragma unroll 1
-    for (int s = 0; s <= nsteps; ++s) {
-        stamp();
-        const bool task_end = s >= 1 && (s - 1) % NCH == NCH - 1;
-        if (s >= 1) {
-            const int sc = s - 1, lt = sc / NCH, c = sc - lt * NCH;
-            int g0n = g0, ty0n = ty0, chn = ch, sn = s_idx;
-            if (task_end && lt + 1 < ntask) task_geo(lt + 1, g0n, ty0n, chn, sn);
+    for (int lt = 0; lt < ntask; ++lt) {
+        int g0n = g0, ty0n = ty0, chn = ch, sn = s_idx;
+        if (lt + 1 < ntask) task_geo(lt + 1, g0n, ty0n, chn, sn);
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {
+            stamp();
+            const int sc = lt * NCH + c;
+            const bool task_end = c == NCH - 1;
             const unsigned char* abase = vbuf + (sc & 1) * W2_V_BYTES + h * 512 + m * 16 + (4 * mi) * 1024;
             const int gnxt = (task_end ? 0 : c + 1) * 16 + 4 * mi;
-            // two frequencies at a time (two independent accumulator chains), then THEIR weights of the next chunk at once, fenced: left
-            // to itself hipcc sinks all twelve weight loads to the end of the step, and the next step starts by waiting an L2 round
-            // trip for them.  Issued here they have at least half a step to land
+            // two frequencies at a time (two independent accumulator chains in flight), each pair followed AT ONCE by the loads of ITS
+            // weights for the next chunk, fenced: left to itself hipcc sinks all twelve weight loads to the end of the step and the next
+            // step starts with an L2 round trip
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {
                 bf16x8 a[2][3], bq[2][3];
@@ -308,35 +322,31 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
             stamp();
-            if (task_end && (DBG & 16)) { w2_barrier(); w2_barrier(); if (acc[0][0] == 1234.5f && acc[1][1] + acc[2][2] + acc[3][3] == 4.0f) out[0] = 1.0f; g0 = g0n; ty0 = ty0n; ch = chn; s_idx = sn; }
-            else if (task_end) {
+            if (!task_end) w2_barrier();
+        }
+        const int sc = lt * NCH + NCH - 1;                              // the task's last chunk: its V buffer becomes the exchange area
+        if (DBG & 16) { w2_barrier(); w2_barrier(); w2_barrier(); if (acc[0][0] == 1234.5f && acc[1][1] + acc[2][2] + acc[3][3] == 4.0f) out[0] = 1.0f; }
+        else {
+            {
                 w2_barrier();                                        // A: every consumer has read its last fragments of V[sc & 1]
                 // column inverse transform (U_{i3} is stored negated); finisher k = row index of slice mn completes accumulator registers
                 // 4 k .. 4 k + 3 (tile column k, tile rows 4 h + e).  Piece (source i -> finisher k): W_i[b][4 k + e] as two float4 (b)
                 float4* const xch = reinterpret_cast<float4*>(vbuf + (sc & 1) * W2_V_BYTES);
                 float own[2][4];
-                {
-                    f32x16 Wc[2];
-                    Wc[0] = acc[0] + acc[1] + acc[2];
-                    Wc[1] = acc[1] - acc[2] + acc[3];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {                          // one b at a time: 16 live registers instead of 32 beside the accumulators
+                    const f32x16 Wc = b == 0 ? acc[0] + acc[1] + acc[2] : acc[1] - acc[2] + acc[3];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         if (k == mi) {
 #pragma unroll
-                            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) own[b][e] = Wc[b][4 * k + e];
+                            for (int e = 0; e < 4; ++e) own[b][e] = Wc[4 * k + e];
                         } else {
                             float4* dst = xch + (size_t)((mn * 4 + mi) * 3 + ((k - mi - 1) & 3)) * 128 + lane;
-#pragma unroll
-                            for (int b = 0; b < 2; ++b) dst[b * 64] = make_float4(Wc[b][4 * k], Wc[b][4 * k + 1], Wc[b][4 * k + 2], Wc[b][4 * k + 3]);
+                            dst[b * 64] = make_float4(Wc[4 * k], Wc[4 * k + 1], Wc[4 * k + 2], Wc[4 * k + 3]);
                         }
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
                 w2_barrier();                                        // B: the pieces are in LDS
                 // Y[0][b] = (W0 + W1) + W2, Y[1][b] = (W1 - W2) - W3: always in THIS order, whichever row the finishing wave holds itself --
                 // the tile column a clip lands on depends on its position in the batch, and a clip's logits must not (bit for bit)
@@ -358,6 +368,8 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                         }
                     }
                 }
+                w2_barrier();                                        // C (this step's closing barrier, early): the pieces are in registers, the producers
+                                                                     // may overwrite this V buffer -- they transform the next chunk while the outputs are finished here
                 const int co = ch * 64 + mn * 32 + m;
                 float ssum = 0.0f, ssq = 0.0f;
                 float sc_ = 1.0f, sh_ = 0.0f;
@@ -419,27 +431,28 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                     ssq += __shfl_xor(ssq, 32);
                     if (h == 0) stats[((size_t)s_idx * 4 + mi) * COUT + co] = make_float2(ssum, ssq);
                 }
-                g0 = g0n; ty0 = ty0n; ch = chn; s_idx = sn;
             }
-        } else {
-            stamp();
         }
-        w2_barrier();
+        g0 = g0n; ty0 = ty0n; ch = chn; s_idx = sn;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
     }
 }
 
 // `attr_done`: the caller's per-device latch of the dynamic-LDS opt-in of THIS instantiation (sir_handle::attr_wino2[...])
-template <int CIN, int COUT, int OUT_MODE, int DBG = 0>
+template <int CIN, int COUT, int OUT_MODE, int DBG = 0, int PRIO = 3>
 static inline hipError_t launch_conv_wino2(hipStream_t st, bool* attr_done, const float* x, const unsigned short* wpb, const float* scale,
                                            const float* shift, float* out, int B, int H, int W, float2* stats, const float* zeros, int max_wg = 256) {
     Wino2Geo g;
     if (!wino2_geo(B, H, W, CIN > COUT ? CIN : COUT, &g)) return hipErrorInvalidValue;
     if (!*attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino2_bf16x6_kernel<CIN, COUT, OUT_MODE, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino2_bf16x6_kernel<CIN, COUT, OUT_MODE, DBG, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS_BYTES);
         if (e != hipSuccess) return e;
         *attr_done = true;
     }
     const int nwg = g.NS < max_wg ? g.NS : max_wg;
-    hipLaunchKernelGGL((conv3x3_wino2_bf16x6_kernel<CIN, COUT, OUT_MODE, DBG>), dim3(nwg), dim3(W2_THREADS), W2_LDS_BYTES, st, x, wpb, scale, shift, out, g, stats, zeros);
+    hipLaunchKernelGGL((conv3x3_wino2_bf16x6_kernel<CIN, COUT, OUT_MODE, DBG, PRIO>), dim3(nwg), dim3(W2_THREADS), W2_LDS_BYTES, st, x, wpb, scale, shift, out, g, stats, zeros);
     return hipGetLastError();
 }

@@ -163,7 +163,7 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     const bool w2ok = wino2_geo(B, 32, d.wp1, 64, &geo2) && wino2_geo(B, 16, d.wp2, 128, &geo3);
     {
         SirProfScope prof(h, SIR_K_CONV2, st);
-        if (w2ok)
+        if (w2ok && (sir_wino2_mask() & 1))
             SIR_HIP_TRY((launch_conv_wino2<32, 64, 0>(st, &h->attr_wino2[0], a1, (const unsigned short*)wcb2, bns + 32, bnt + 32, a2, B, 32, d.wp1,
                                                     (float2*)nullptr, h->zero_page, h->num_cus)));
         else
@@ -174,7 +174,7 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
         // conv3 stores straight into the GRU input layout [B][S][c*8+h] (models.py:55-57) and writes the bf16x3 planes of
         // the first input projection's A operand beside it
         SirProfScope prof(h, SIR_K_CONV3, st);
-        if (w2ok)
+        if (w2ok && (sir_wino2_mask() & 2))
             SIR_HIP_TRY((launch_conv_wino2<64, 128, 1>(st, &h->attr_wino2[1], a2, (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, B, 16, d.wp2,
                                                      (float2*)xs, h->zero_page, h->num_cus)));
         else

@@ -224,7 +224,8 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     // conv2 / conv3 forward and the conv3 data gradient run on the producer / consumer Winograd kernel (conv_wino2_bf16x6_kernel.h);
     // shapes it does not cover keep the first-generation / direct kernels
     Wino2Geo geo2, geo3;
-    const bool w2ok = wino2_geo(B, 32, d.wp1, 64, &geo2) && wino2_geo(B, 16, d.wp2, 128, &geo3);
+    const bool w2ok_all = wino2_geo(B, 32, d.wp1, 64, &geo2) && wino2_geo(B, 16, d.wp2, 128, &geo3);
+    const bool w2c2 = w2ok_all && (sir_wino2_mask() & 1), w2c3 = w2ok_all && (sir_wino2_mask() & 2);
     {   // all weight re-layouts of this step, the backward's included (the weights do not change before it runs)
         SirProfScope prof(h, SIR_K_T_PREP, st);
         PrepJobs pj{};
@@ -235,7 +236,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
         };
         add(4, w->conv_w[1], p.wcb2, 32, 64, (32 * 16 * 64 + 255) / 256);       // conv2 forward: Winograd frequencies
         add(4, w->conv_w[2], p.wcb3, 64, 128, (64 * 16 * 128 + 255) / 256);     // conv3 forward: Winograd frequencies
-        if (!w2ok) add(1, w->conv_w[2], p.wcb3d, 64, 128, (64 * 9 * 128 + 255) / 256);
+        if (!w2c3) add(1, w->conv_w[2], p.wcb3d, 64, 128, (64 * 9 * 128 + 255) / 256);
         add(2, w->conv_w[1], p.wcb2t, 32, 64, (32 * 9 * 64 + 255) / 256);
         add(5, w->conv_w[2], p.wcb3t, 64, 128, (128 * 16 * 64 + 255) / 256);   // conv3 data gradient: Winograd frequencies of the flipped taps
         for (int dir = 0; dir < 2; ++dir) {
@@ -268,7 +269,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     // conv2 block: raw conv + partial statistics on MFMA, finalize, BN+ReLU+pool
     {
         { SirProfScope prof(h, SIR_K_T_CONV2, st);
-        if (w2ok)
+        if (w2c2)
             SIR_HIP_TRY((launch_conv_wino2<32, 64, 2>(st, &h->attr_wino2[2], (const float*)p.a1, (const unsigned short*)p.wcb2, (const float*)nullptr,
                                                     (const float*)nullptr, p.z2, B, 32, d.wp1, p.stats, h->zero_page, h->num_cus)));
         else
@@ -276,7 +277,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
                                (const unsigned short*)p.wcb2, (const float*)nullptr, (const float*)nullptr, p.z2, 32, d.wp1, 16, d.wp2, p.stats);
         }
         SirProfScope prof(h, SIR_K_T_BN2, st);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, w2ok ? (int)wino2_stat_blocks(B, 32, d.wp1) : d.c2wx * B, 64,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, w2c2 ? (int)wino2_stat_blocks(B, 32, d.wp1) : d.c2wx * B, 64,
                            (double)B * 32 * d.wp1, w->bn_w[1], w->bn_b[1], bn_running_mean[1], bn_running_var[1], bn_momentum,
                            scale + 32, shift + 32, smean + 32, sinv + 32);
         hipLaunchKernelGGL(bn_relu_pool_kernel<false>, dim3(grid_for((size_t)B * 16 * d.wp2 * 16)), dim3(256), 0, st, p.z2,
@@ -284,7 +285,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     }
     {
         { SirProfScope prof(h, SIR_K_T_CONV3, st);
-        if (w2ok)
+        if (w2c3)
             SIR_HIP_TRY((launch_conv_wino2<64, 128, 2>(st, &h->attr_wino2[3], (const float*)p.a2, (const unsigned short*)p.wcb3, (const float*)nullptr,
                                                      (const float*)nullptr, p.z3, B, 16, d.wp2, p.stats, h->zero_page, h->num_cus)));
         else
@@ -292,7 +293,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
                                (const unsigned short*)p.wcb3d, (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats);
         }
         SirProfScope prof(h, SIR_K_T_BN3, st);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, w2ok ? (int)wino2_stat_blocks(B, 16, d.wp2) : d.c3fx * B, 128,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, w2c3 ? (int)wino2_stat_blocks(B, 16, d.wp2) : d.c3fx * B, 128,
                            (double)B * 16 * d.wp2, w->bn_w[2], w->bn_b[2], bn_running_mean[2], bn_running_var[2], bn_momentum,
                            scale + 96, shift + 96, smean + 96, sinv + 96);
         hipLaunchKernelGGL(bn_relu_pool_kernel<true>, dim3(grid_for((size_t)B * 8 * d.wp3 * 32)), dim3(256), 0, st, p.z3,
@@ -515,7 +516,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             // of 8 x 4 tiles for the 16-row map, raw output (train_prep_kernel of the forward built p.wcb3t)
             SirProfScope prof(h, SIR_K_B_DGRAD3, st);
             Wino2Geo geo3b;
-            if (wino2_geo(B, 16, d.wp2, 128, &geo3b))
+            if (wino2_geo(B, 16, d.wp2, 128, &geo3b) && (sir_wino2_mask() & 4))
                 SIR_HIP_TRY((launch_conv_wino2<128, 64, 3>(st, &h->attr_wino2[4], (const float*)p.dz3, (const unsigned short*)p.wcb3t, (const float*)nullptr,
                                                          (const float*)nullptr, p.da2, B, 16, d.wp2, (float2*)nullptr, h->zero_page, h->num_cus)));
             else

@@ -156,6 +156,10 @@ static inline int sir_cluster_leave(sir_handle* h, hipStream_t st) {
     return SIR_OK;
 }
 
+// SIR_WINO2 (default 7): bit 0 = conv2, bit 1 = conv3, bit 2 = conv3 data gradient on the producer / consumer Winograd kernel
+// (conv_wino2_bf16x6_kernel.h); a cleared bit keeps the first-generation / direct kernel of that stage (A/B on one box:
+// devtools/gpu_ab_wino2.sh, profiles/r03/ab_wino2.txt)
+int sir_wino2_mask();
 void sir_set_error(const char* fmt, ...);
 int sir_check_hip(hipError_t e, const char* what);
 
