@@ -394,12 +394,14 @@ int main(int argc, char** argv) {
             run_wino2<64, 128, 2, 2, 1, false, 2>("conv3 GRU layout + planes", 256, 16, 50);
             run_wino2<64, 128, 2, 2, 2, false, 2>("conv3 raw + stats", 256, 16, 50);
             run_wino2<128, 64, 2, 4, 3, true, 2>("conv3 data gradient", 256, 16, 50);
+            run_wino2<64, 32, 4, 2, 3, true, 4>("conv2 data gradient", 256, 32, 100);
         }
         run_wino2<32, 64, 4, 2, 0, false, 3>("conv2 pooled, ragged", 3, 32, 47);
         run_wino2<32, 64, 4, 2, 2, false, 3>("conv2 raw, ragged", 5, 32, 47);
         run_wino2<64, 128, 2, 2, 1, false, 2>("conv3 GRU layout, ragged", 3, 16, 23);
         run_wino2<64, 128, 2, 2, 2, false, 2>("conv3 raw, ragged", 1, 16, 15);
         run_wino2<128, 64, 2, 4, 3, true, 2>("conv3 data gradient, ragged", 5, 16, 23);
+        run_wino2<64, 32, 4, 2, 3, true, 4>("conv2 data gradient, ragged", 3, 32, 47);
         return 0;
     }
     if (argc > 1 && std::string(argv[1]) == "loop") { load_loop(argc > 2 ? atof(argv[2]) : 3.0); return 0; }

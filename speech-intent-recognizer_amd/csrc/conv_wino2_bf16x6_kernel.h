@@ -103,8 +103,8 @@ template <int CIN, int COUT, int OUT_MODE, int DBG = 0, int PRIO = 3>
 __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpb, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, Wino2Geo geo, float2* __restrict__ stats, const float* __restrict__ zeros) {
-    constexpr int NCH = CIN / 16, G = NCH * 16, NCHO = COUT / 64;
-    static_assert(CIN % 16 == 0 && COUT % 64 == 0, "16-channel chunks, 64-channel tasks");
+    constexpr int NCH = CIN / 16, G = NCH * 16, NCHO = COUT >= 64 ? COUT / 64 : 1;
+    static_assert(CIN % 16 == 0 && (COUT % 64 == 0 || COUT == 32), "16-channel chunks; 64-channel tasks (32: the n = 1 consumer waves only keep the barriers)");
     extern __shared__ __attribute__((aligned(1024))) unsigned char w2s[];
     unsigned char* const vbuf = w2s;                                    // [2][3 planes][16 f][1 KB]
     unsigned char* const rawbuf = w2s + 2 * W2_V_BYTES;                 // [3][13 KB]
@@ -211,33 +211,39 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                 for (int rr = 0; rr < 3; ++rr) w2_read_row(rb + ra_rel[rr], q[rr][0], q[rr][1], q[rr][2], q[rr][3]);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (edge) {                                             // (one task in ~12: the halo column belongs to the neighbouring image)
+                    // a real branch (the asm keeps hipcc from turning it into 48 selects on the common path): multiply by 0 / 1
+                    const float k0 = z0 ? 0.0f : 1.0f, k3 = z3 ? 0.0f : 1.0f;
+                    asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int rr = 0; rr < 3; ++rr) {
-                        if (z0) q[rr][0] = (w2_f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (z3) q[rr][3] = (w2_f32x4){0.f, 0.f, 0.f, 0.f};
-                    }
+                    for (int rr = 0; rr < 3; ++rr) { q[rr][0] *= k0; q[rr][3] *= k3; }
                 }
-                // patch rows tR .. tR + 2 (row pair 0: i = 0: d0 - d2, i = 1: d1 + d2; pair 1 (rows 1,2,3): i = 2: d2 - d1, i = 3: d1 - d3)
+                // patch rows tR .. tR + 2 (row pair 0: i = 0: d0 - d2, i = 1: d1 + d2; pair 1 (rows 1,2,3): i = 2: d2 - d1, i = 3: d1 - d3).
+                // tR is wave-uniform: two straight-line copies under a branch (as one body hipcc computed both and selected: 32 v_cndmask)
+                auto rows = [&](auto trc) {
+                    constexpr int TR = decltype(trc)::value;
 #pragma unroll
-                for (int il = 0; il < 2; ++il) {
-                    w2_f32x4 R[4];
+                    for (int il = 0; il < 2; ++il) {
+                        w2_f32x4 R[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (tR == 0) R[j] = il == 0 ? q[0][j] - q[2][j] : q[1][j] + q[2][j];
-                        else         R[j] = il == 0 ? q[1][j] - q[0][j] : q[0][j] - q[2][j];
+                        for (int j = 0; j < 4; ++j) {
+                            if (TR == 0) R[j] = il == 0 ? q[0][j] - q[2][j] : q[1][j] + q[2][j];
+                            else         R[j] = il == 0 ? q[1][j] - q[0][j] : q[0][j] - q[2][j];
+                        }
+                        const w2_f32x4 V[4] = {R[0] - R[2], R[1] + R[2], R[2] - R[1], R[1] - R[3]};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            uint2 sh, sm, sl;
+                            split3_pair(V[j].x, V[j].y, sh.x, sm.x, sl.x);
+                            split3_pair(V[j].z, V[j].w, sh.y, sm.y, sl.y);
+                            const unsigned d = vd + (4 * il + j) * 1024;
+                            w2_write64<0>(d, sh);
+                            w2_write64<W2_PLB>(d, sm);
+                            w2_write64<2 * W2_PLB>(d, sl);
+                        }
                     }
-                    const w2_f32x4 V[4] = {R[0] - R[2], R[1] + R[2], R[2] - R[1], R[1] - R[3]};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        uint2 sh, sm, sl;
-                        split3_pair(V[j].x, V[j].y, sh.x, sm.x, sl.x);
-                        split3_pair(V[j].z, V[j].w, sh.y, sm.y, sl.y);
-                        const unsigned d = vd + (4 * il + j) * 1024;
-                        w2_write64<0>(d, sh);
-                        w2_write64<W2_PLB>(d, sm);
-                        w2_write64<2 * W2_PLB>(d, sl);
-                    }
-                }
+                };
+                if (tR == 0) rows(std::integral_constant<int, 0>{});
+                else rows(std::integral_constant<int, 1>{});
                 }
                 // chunk s + 1 (issued a step ago) must have landed before the barrier; the pieces of chunk s + 2, just issued, may still fly
                 // (a wave issues 3 or 4 pieces per chunk: allowing its 3 newest operations to be outstanding is safe for both)
@@ -254,6 +260,13 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
     // ================= consumers ==================================================================================================
     // wave (n = cw & 1, i = cw >> 1): channel slice 32 n.., transform row i (frequencies 4 i .. 4 i + 3, 4 accumulators)
     const int cw = wv - 4, mn = cw & 1, mi = cw >> 1, m = lane & 31, h = lane >> 5;
+    if (COUT < 64 && mn == 1) {                                         // a 32-channel layer has no second slice: join the barriers, nothing else
+        w2_barrier();
+        w2_barrier();
+        for (int lt = 0; lt < ntask; ++lt)
+            for (int c = 0; c < NCH + 2; ++c) w2_barrier();
+        return;
+    }
     // U fragment address = uniform part (plane, frequency, channel block, slice: scalar registers) + this lane's 32-bit byte offset
     const unsigned wlane = (unsigned)((m * 2 + h) * 16);
     const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(wpb) + (size_t)mn * 1024;
