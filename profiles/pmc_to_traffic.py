@@ -18,6 +18,11 @@ import sys
 
 NAME_MAP = [
     # training-only instantiations first (substring match, first hit wins)
+    # second-generation Winograd kernel <CIN, COUT, OUT_MODE, ...>: mode 2 = training forward, 3 = data gradient, 0 / 1 = inference
+    ("conv3x3_wino2_bf16x6_kernel<32, 64, 2", "train_conv2_fwd"), ("conv3x3_wino2_bf16x6_kernel<64, 128, 2", "train_conv3_fwd"),
+    ("conv3x3_wino2_bf16x6_kernel<128, 64, 3", "bwd_conv3_dgrad"),
+    ("conv3x3_wino2_bf16x6_kernel<32, 64, 0", "conv2_mfma_bn_relu_pool"), ("conv3x3_wino2_bf16x6_kernel<64, 128, 1", "conv3_mfma_bn_relu_pool"),
+    ("conv3x3_wino_bf16x6_kernel<128, 64", "bwd_conv3_dgrad"),
     ("conv3x3_wino_bf16x6_kernel<32, 64, 2", "train_conv2_fwd"), ("conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 2", "train_conv3_fwd"),
     ("conv3x3_bf16x6_ns_kernel<64, 32", "bwd_conv2_dgrad"), ("conv3x3_bf16x6_ns_kernel<128, 64", "bwd_conv3_dgrad"),
     ("conv_wgrad_bf16x6_kernel<32, 64>", "bwd_conv2_wgrad"), ("conv_wgrad_bf16x6_kernel<64, 128>", "bwd_conv3_wgrad"),

@@ -37,6 +37,9 @@ GI = B * S * 1536 * 4
 Y = B * S * 512 * 4
 ROWS = [
     # ---- training step ----
+    ("conv3x3_wino2_bf16x6_kernel<32, 64, 2", "train conv2 fwd (Winograd 2nd gen, raw out + BN partials)", "train", "mfma6", F["train_conv2_fwd"] * B, A1 + Z2),
+    ("conv3x3_wino2_bf16x6_kernel<64, 128, 2", "train conv3 fwd (Winograd 2nd gen, raw out + BN partials)", "train", "mfma6", F["train_conv3_fwd"] * B, A2 + Z3),
+    ("conv3x3_wino2_bf16x6_kernel<128, 64, 3", "bwd conv3 dgrad (Winograd 2nd gen)", "train", "mfma6", F["bwd_conv3_dgrad"] * B, Z3 + A2),
     ("conv3x3_wino_bf16x6_kernel<32, 64, 2", "train conv2 fwd (Winograd, raw out + BN partials)", "train", "mfma6", F["train_conv2_fwd"] * B, A1 + Z2),
     ("conv3x3_wino_bf16x6_kernel<64, 128, 2", "train conv3 fwd (Winograd, raw out + BN partials)", "train", "mfma6", F["train_conv3_fwd"] * B, A2 + Z3),
     ("conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 2", "train conv3 fwd (direct, raw out + BN partials)", "train", "mfma6", F["train_conv3_fwd"] * B, A2 + Z3),
@@ -63,6 +66,8 @@ ROWS = [
     ("gemm_nt_bf16x6_v3_kernel", "input projections (l0, l1: mean)", "both", "mfma6", (F["gemm_ih_l0"] + F["gemm_ih_l1"]) * B // 2,
      (X0 + Y) * 3 // 4 + GI),
     # ---- inference ----
+    ("conv3x3_wino2_bf16x6_kernel<32, 64, 0", "conv2 + BN + ReLU + pool (Winograd 2nd gen)", "infer", "mfma6", F["conv2_mfma_bn_relu_pool"] * B, A1 + A2),
+    ("conv3x3_wino2_bf16x6_kernel<64, 128, 1", "conv3 + BN + ReLU + pool (Winograd 2nd gen)", "infer", "mfma6", F["conv3_mfma_bn_relu_pool"] * B, A2 + X0 + X0 * 3 // 2),
     ("feat_utt_kernel", "feature kernel (waveform -> normalised log-mel)", "infer", "hbm", None, bench.FEATURE_BYTES_PER_UTT * B),
     ("conv1_conv2_fused", "conv1+conv2 fused (Winograd)", "infer", "mfma6", (F["conv1_bn_relu_pool"] + F["conv2_mfma_bn_relu_pool"]) * B, FEAT + A2),
     ("conv1_mfma_bn_relu_pool_kernel", "conv1 + BN + ReLU + pool (f32 MFMA)", "infer", "hbm", None, FEAT + A1),
