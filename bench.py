@@ -330,15 +330,29 @@ class GpuSensors:
         import glob
         self.period = period
         self.power_file = self.sclk_file = None
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
-        cards = [c for c in cards if os.path.exists(os.path.join(c, "power1_average")) or os.path.exists(os.path.join(c, "power1_input"))]
-        if index < len(cards):
+        self.how = None
+        hw = None
+        # the card of THIS process: by PCI address (sysfs lists every GPU of the host, the process sees one), else by position
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            cand = sorted(glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*"))
+            if cand:
+                hw, self.how = cand[0], f"amdgpu hwmon (sysfs) of PCI device {bdf}"
+        except Exception:
+            pass
+        if hw is None:
+            cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+            cards = [c for c in cards if os.path.exists(os.path.join(c, "power1_average")) or os.path.exists(os.path.join(c, "power1_input"))]
+            if index < len(cards):
+                hw, self.how = cards[index], f"amdgpu hwmon (sysfs), card position {index} (PCI address not available: may be another GPU of the host)"
+        if hw is not None:
             for name in ("power1_average", "power1_input"):
-                f = os.path.join(cards[index], name)
+                f = os.path.join(hw, name)
                 if os.path.exists(f):
                     self.power_file = f
                     break
-            f = os.path.join(cards[index], "freq1_input")
+            f = os.path.join(hw, "freq1_input")
             self.sclk_file = f if os.path.exists(f) else None
         self.samples = []
         self._stop = None
@@ -369,7 +383,7 @@ class GpuSensors:
         self._thread.join()
 
     def summary(self):
-        out = {"samples": len(self.samples), "source": "amdgpu hwmon (sysfs)" if self.power_file or self.sclk_file else None}
+        out = {"samples": len(self.samples), "source": self.how if self.power_file or self.sclk_file else None}
         for i, key in enumerate(("power_W", "sclk_MHz")):
             v = [s[i] for s in self.samples if s[i] is not None]
             out[key] = {"mean": round(sum(v) / len(v), 1), "max": round(max(v), 1), "min": round(min(v), 1)} if v else None

@@ -281,7 +281,7 @@ static void run_wino2(const char* name, int B, int H, int W, int reps = 60) {
     CK_(hipMalloc(&dx, nx * 4)); CK_(hipMalloc(&dw, nw * 4)); CK_(hipMalloc(&ds, COUT * 4)); CK_(hipMalloc(&dt, COUT * 4));
     CK_(hipMalloc(&o1, nout * 4)); CK_(hipMalloc(&o2, nout * 4)); CK_(hipMalloc(&wpb, nw * 6)); CK_(hipMalloc(&wpw, (size_t)COUT * CIN * 16 * 6));
     if (MODE == 1) { CK_(hipMalloc(&pl1, nout * 6)); CK_(hipMalloc(&pl2, nout * 6)); CK_(hipMemset(pl1, 0, nout * 6)); CK_(hipMemset(pl2, 0, nout * 6)); }
-    if (MODE == 2) { CK_(hipMalloc(&st1, (size_t)gd.x * gd.y * B * COUT * 8)); CK_(hipMalloc(&st2, (size_t)geo.NS * 4 * COUT * 8)); }
+    if (MODE == 2) { CK_(hipMalloc(&st1, (size_t)gd.x * gd.y * B * COUT * 8)); CK_(hipMalloc(&st2, wino2_stat_blocks(B, H, W, 256) * COUT * 8)); }
     CK_(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
     CK_(hipMemcpy(ds, hs.data(), COUT * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(dt, ht.data(), COUT * 4, hipMemcpyHostToDevice));
     hipStream_t st; CK_(hipStreamCreate(&st));
@@ -330,7 +330,7 @@ static void run_wino2(const char* name, int B, int H, int W, int reps = 60) {
             printf("  bf16x3 planes (hi + mid + lo): max difference %.3e\n", dp);
         }
         if (MODE == 2) {
-            const size_t n1 = (size_t)gd.x * gd.y * B, n2 = (size_t)geo.NS * 4;
+            const size_t n1 = (size_t)gd.x * gd.y * B, n2 = wino2_stat_blocks(B, H, W, 256);
             std::vector<float2> s1(n1 * COUT), s2(n2 * COUT);
             CK_(hipMemcpy(s1.data(), st1, s1.size() * 8, hipMemcpyDeviceToHost)); CK_(hipMemcpy(s2.data(), st2, s2.size() * 8, hipMemcpyDeviceToHost));
             double worst = 0;

@@ -137,7 +137,7 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     if (rc == SIR_OK) rc = upload(&h->zero_page, std::vector<float>(1024, 0.0f));
     if (rc == SIR_OK) {
         int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->num_cus = cus;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->num_cus = cus < 1024 ? cus : 1024;
     }
     if (rc == SIR_OK) rc = sir_check_hip(hipEventCreateWithFlags(&h->cluster_done, hipEventDisableTiming), "hipEventCreate");
     if (rc != SIR_OK) { sir_destroy(h); return rc; }

@@ -28,7 +28,7 @@
 //   epilogue      column inverse transform in registers, row transform across the four consumer waves of a channel slice through
 //                 the V buffer the task's last chunk just left (each wave finishes one tile column: it receives 3 x 2 KB; two
 //                 extra barriers per task), then BN + ReLU + 2x2 max (the 2x2 outputs of a tile ARE the pooling window) or raw
-//                 outputs (+ per-(task, tile column) channel statistics).
+//                 outputs (+ channel statistics, accumulated in registers over the workgroup's tasks: 4 blocks per workgroup).
 // Weights: prep_conv_w_wino_bf16x3 layout wpb[plane][chunk * 16 + f][cout][16 ch] with column j = 3 negated (shared with the
 // first generation); data gradients use the same kernel on the transposed / flipped taps (prep_conv_wT_wino_bf16x3).
 // Measured (devtools/kernel_ab/bench_conv.hip `wino2`, batch 256, four rotating inputs, one box): conv2 143 us against 184 direct
@@ -70,11 +70,14 @@ static inline bool wino2_geo(int B, int H, int W, int cmax, Wino2Geo* g) {
     g->NS = g->RBN * ((g->NG + 3) / 4); g->Hp = H / 2; g->Wp = W / 2;
     return H % 16 == 0 && W >= 1 && B >= 1 && (size_t)B * H * W * cmax < ((size_t)1 << 31) && (size_t)g->NG * 2 < ((size_t)1 << 30);
 }
-// per-(task, tile column) statistics blocks of OUT_MODE 2
-static inline size_t wino2_stat_blocks(int B, int H, int W) { return (size_t)(H / 16) * (((size_t)B * ((W + 1) / 2) + 3) / 4) * 4; }
+// statistics blocks of OUT_MODE 2: one per (workgroup, transform-row wave); `max_wg` as passed to launch_conv_wino2
+static inline size_t wino2_stat_blocks(int B, int H, int W, int max_wg) {
+    const size_t ns = (size_t)(H / 16) * (((size_t)B * ((W + 1) / 2) + 3) / 4);
+    return (ns < (size_t)max_wg ? ns : (size_t)max_wg) * 4;
+}
 
 // OUT_MODE 0: pooled NHWC (BN + ReLU + max), 1: pooled in the GRU layout [b][tx][co * Hp + ty] (+ its bf16x3 planes through
-// `stats`), 2: raw NHWC + per-task channel statistics (float2 {sum, sum of squares} at stats[task * COUT + co]), 3: raw NHWC
+// `stats`), 2: raw NHWC + channel statistics (float2 {sum, sum of squares} at stats[(workgroup * 4 + row wave) * COUT + co]), 3: raw NHWC
 // ---- LDS access behind the compiler's back (producer waves) ---------------------------------------------------------------
 // hipcc orders every LDS read / write it can see behind ALL outstanding LDS-DMA of the wave (s_waitcnt vmcnt(0): it cannot prove
 // that the DMA target and the access do not alias) and w2_barrier() drains vmcnt as well.  The producers keep two chunks of
@@ -286,6 +289,9 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
     w2_barrier();                                                    // (pairs with the producers' "raw chunks 0 and 1 have landed")
+    float run_s[NCHO], run_q[NCHO];                                    // OUT_MODE 2: channel statistics of this wave's outputs, per channel block, over ALL its tasks
+#pragma unroll
+    for (int k = 0; k < NCHO; ++k) { run_s[k] = 0.0f; run_q[k] = 0.0f; }
 
     stamp();
     stamp();
@@ -439,10 +445,10 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                                 }
                     }
                 }
-                if (OUT_MODE == 2 && stats) {                           // one partial per (task, tile column): 4 NS blocks of COUT
-                    ssum += __shfl_xor(ssum, 32);
-                    ssq += __shfl_xor(ssq, 32);
-                    if (h == 0) stats[((size_t)s_idx * 4 + mi) * COUT + co] = make_float2(ssum, ssq);
+                if (OUT_MODE == 2) {                                     // (kept in registers across the tasks: one partial per workgroup and row wave)
+#pragma unroll
+                    for (int k = 0; k < NCHO; ++k)
+                        if (k == ch) { run_s[k] += ssum; run_q[k] += ssq; }
                 }
             }
         }
@@ -451,6 +457,16 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    }
+    if (OUT_MODE == 2 && stats) {
+        // statistics block (workgroup, row wave): 4 gridDim.x blocks of COUT channels in all (wino2_stat_blocks), fixed summation order
+#pragma unroll
+        for (int k = 0; k < NCHO; ++k) {
+            float a = run_s[k], q = run_q[k];
+            a += __shfl_xor(a, 32);
+            q += __shfl_xor(q, 32);
+            if (h == 0) stats[((size_t)blockIdx.x * 4 + mi) * COUT + k * 64 + mn * 32 + m] = make_float2(a, q);
+        }
     }
 }
 

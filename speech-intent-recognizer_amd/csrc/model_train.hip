@@ -86,8 +86,8 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     size_t st = (size_t)d.c1gx * d.c1gy * B * 32;                       // conv1 partials (float2)
     // per-(task, tile column) statistics of the producer / consumer Winograd kernel (or per-workgroup ones of the fallback kernels)
     size_t s2 = (size_t)d.c2wx * B * 64, s3 = (size_t)d.c3fx * B * 128;
-    if (wino2_stat_blocks(d.B, 32, d.wp1) * 64 > s2) s2 = wino2_stat_blocks(d.B, 32, d.wp1) * 64;
-    if (wino2_stat_blocks(d.B, 16, d.wp2) * 128 > s3) s3 = wino2_stat_blocks(d.B, 16, d.wp2) * 128;
+    if ((size_t)4 * 1024 * 64 > s2) s2 = (size_t)4 * 1024 * 64;         // (4 blocks per workgroup, at most 1024 workgroups = CUs)
+    if ((size_t)4 * 1024 * 128 > s3) s3 = (size_t)4 * 1024 * 128;
     if (s2 > st) st = s2;
     if (s3 > st) st = s3;
     const size_t bw = (size_t)(B * 16 * d.wp1 / 64 + 64) * 128;          // bn backward partials, generous
@@ -277,7 +277,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
                                (const unsigned short*)p.wcb2, (const float*)nullptr, (const float*)nullptr, p.z2, 32, d.wp1, 16, d.wp2, p.stats);
         }
         SirProfScope prof(h, SIR_K_T_BN2, st);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, w2c2 ? (int)wino2_stat_blocks(B, 32, d.wp1) : d.c2wx * B, 64,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, w2c2 ? (int)wino2_stat_blocks(B, 32, d.wp1, h->num_cus) : d.c2wx * B, 64,
                            (double)B * 32 * d.wp1, w->bn_w[1], w->bn_b[1], bn_running_mean[1], bn_running_var[1], bn_momentum,
                            scale + 32, shift + 32, smean + 32, sinv + 32);
         hipLaunchKernelGGL(bn_relu_pool_kernel<false>, dim3(grid_for((size_t)B * 16 * d.wp2 * 16)), dim3(256), 0, st, p.z2,
@@ -293,7 +293,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
                                (const unsigned short*)p.wcb3d, (const float*)nullptr, (const float*)nullptr, p.z3, 16, d.wp2, 8, d.wp3, p.stats);
         }
         SirProfScope prof(h, SIR_K_T_BN3, st);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, w2c3 ? (int)wino2_stat_blocks(B, 16, d.wp2) : d.c3fx * B, 128,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, w2c3 ? (int)wino2_stat_blocks(B, 16, d.wp2, h->num_cus) : d.c3fx * B, 128,
                            (double)B * 16 * d.wp2, w->bn_w[2], w->bn_b[2], bn_running_mean[2], bn_running_var[2], bn_momentum,
                            scale + 96, shift + 96, smean + 96, sinv + 96);
         hipLaunchKernelGGL(bn_relu_pool_kernel<true>, dim3(grid_for((size_t)B * 8 * d.wp3 * 32)), dim3(256), 0, st, p.z3,

@@ -181,3 +181,19 @@ def test_teardown_in_any_order_exits_cleanly(order, backend, tmp_path):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "TEARDOWN-OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("mask", ["0", "5"])
+def test_fallback_conv_kernels_keep_parity(mask):
+    """SIR_WINO2 selects per stage between the producer / consumer Winograd kernel (default: conv2, conv3, conv3 data gradient) and
+    the first-generation / direct kernels, which shapes outside the new kernel's range still use.  The switch is read once per
+    process, so the reference-golden inference and training-step tests run again in a child with the stages switched off
+    (0) or mixed (5: conv3 direct, the others on): both sets of kernels stay correct."""
+    env = dict(os.environ, SIR_WINO2=mask)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu",
+                        os.path.join(ROOT, "tests", "test_model_gpu.py::test_eval_golden_from_reference"),
+                        os.path.join(ROOT, "tests", "test_model_gpu.py::test_stages_vs_oracle"),
+                        os.path.join(ROOT, "tests", "test_train_gpu.py::test_train_step_matches_reference_golden"),
+                        os.path.join(ROOT, "tests", "test_train_gpu.py::test_train_forward_backward_stages")],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
