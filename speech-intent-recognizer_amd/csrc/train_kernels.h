@@ -36,7 +36,8 @@ __device__ __forceinline__ void c1_moments_accum(const float (&v)[9], float (&m)
     }
 }
 
-// block (g, b) walks the 8 x 64-pixel tiles g, g + gridDim.x, ... of image b; part[b * gridDim.x + g][54]
+// block (g, b) walks the 8 x 64-pixel tiles g, g + gridDim.x, ... of image b; part[54][gridDim.y * gridDim.x] (moment-major: the
+// reduce kernel then reads contiguous rows -- block-major rows of 54 floats made it a 216-byte-stride gather, 37 us for 442 KB)
 static __global__ __launch_bounds__(256) void conv1_moments_kernel(const float* __restrict__ x, float* __restrict__ part, int H, int W,
                                                                     int tiles_x, int tiles_y) {
     __shared__ float tile[C1_TR * C1_TC];
@@ -71,13 +72,13 @@ static __global__ __launch_bounds__(256) void conv1_moments_kernel(const float* 
             }
         }
     }
-    const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
+    const size_t blk = (size_t)b * gridDim.x + blockIdx.x, nblk = (size_t)gridDim.x * gridDim.y;
 #pragma unroll
     for (int i = 0; i < C1_MPW; ++i) {
         float a = m[i];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-        if (lane == 0 && C1_MPW * wv + i < C1_NMOM) part[blk * C1_NMOM + C1_MPW * wv + i] = a;
+        if (lane == 0 && C1_MPW * wv + i < C1_NMOM) part[(size_t)(C1_MPW * wv + i) * nblk + blk] = a;
     }
 }
 
@@ -87,7 +88,7 @@ static __global__ __launch_bounds__(256) void conv1_moments_reduce_kernel(const 
     const int i = blockIdx.x, tid = threadIdx.x;
     double s = 0.0;
 #pragma unroll 8
-    for (int r = tid; r < nblk; r += 256) s += part[(size_t)r * C1_NMOM + i];
+    for (int r = tid; r < nblk; r += 256) s += part[(size_t)i * nblk + r];
     rs[tid] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
