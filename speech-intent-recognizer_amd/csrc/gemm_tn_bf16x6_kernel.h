@@ -21,6 +21,7 @@
 #include "bf16x6_kernels.h"
 
 constexpr int TN_BM = 128, TN_BN = 256, TN_BK = 32;
+constexpr int TN_BM_DW = 256;                               // row tile of the weight-gradient launches (dW = dG^T X)
 constexpr int TN_ROWB = TN_BK * 2 + 16;                      // k-contiguous image (A of dX): 80 B per row, 5 sixteen-byte slots (odd -> conflict-free b128 reads)
 // k-major image of an operand given as [k][x] (x contiguous): per plane 32 rows of 2 X bytes, 64-byte chunks swizzled
 constexpr size_t tn_lds_bytes(bool a_km, int bm) {
@@ -28,6 +29,7 @@ constexpr size_t tn_lds_bytes(bool a_km, int bm) {
 }
 constexpr size_t TN_LDS_BYTES = tn_lds_bytes(false, 128);    // 79,872 B: the larger of the two BM = 128 instantiations (dW: 73,728)
 constexpr size_t TN_LDS_BYTES_64 = tn_lds_bytes(false, 64);  // 64,512 B (BM = 64)
+constexpr size_t TN_LDS_BYTES_256 = tn_lds_bytes(true, 256); // 98,304 B (dW with 256-row tiles: one workgroup per CU)
 
 // byte offset of element (row k, byte xb of the row) in a k-major image with XW-byte rows.  The four rows k0 .. k0+3 of a
 // transposed read (k0 a multiple of 4) put their 64-byte chunk on four different quarters of the 256-byte bank line:
@@ -72,8 +74,9 @@ struct TnJobs {
 // that would otherwise leave most CUs idle (layer-1 dX: 6400 x 512 is only 100 tiles of 128 x 256).
 template <bool A_KM, int BM = TN_BM>
 __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M, int K, int kchunk, int seq) {
-    static_assert(BM == 128 || BM == 64, "tile rows");
-    constexpr int NC = BM == 128 ? 2 : 1;                    // 32-column accumulators per wave
+    static_assert(BM == 256 || BM == 128 || BM == 64, "tile rows");
+    constexpr int NC = BM >= 128 ? 2 : 1;                    // 32-column accumulators per wave
+    constexpr int NA = BM == 256 ? 4 : 2, WMR = 32 * NA;     // 32-row accumulators per wave; rows of a wave tile
     constexpr int NAQ = BM * 8 / 512;                        // A staging items per thread
     constexpr int AXW = BM * 2, BXW = TN_BN * 2;             // row bytes of the k-major images
     constexpr int APLANE = A_KM ? TN_BK * AXW : BM * TN_ROWB, BPLANE = TN_BK * BXW;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
     const int brows = jobs.brows[j];
     const int k_begin = blockIdx.y * kchunk, k_end = min(K, k_begin + kchunk);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = BM == 128 ? wv >> 2 : 0, wn = BM == 128 ? wv & 3 : wv, i32 = lane & 31, kgrp = lane >> 5;
+    const int wm = BM >= 128 ? wv >> 2 : 0, wn = BM >= 128 ? wv & 3 : wv, i32 = lane & 31, kgrp = lane >> 5;
 
     // staging items, lanes along the columns (coalesced 16-byte loads, 128 contiguous LDS bytes per 16-lane store group):
     //   A_KM : A item = (4-column group it % (BM/4), token it / (BM/4)); else A item = (row it / 8, four consecutive k)
@@ -148,9 +151,9 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
         }
     };
 
-    f32x16 acc[2][NC];
+    f32x16 acc[NA][NC];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -161,12 +164,12 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
     // (lane & 15).  For the 32 x 32 x 16 operand, group g covers columns 16 (g & 1) .. + 15 of the wave's 32-column tile
     // and k = 8 (g >> 1) .. + 7 of the 16-deep step (two reads: k .. k + 3, k + 4 .. k + 7).
     const int tq = (lane >> 2) & 3, tp = lane & 3, tcol = 16 * ((lane >> 4) & 1) + 4 * tp, tk = 8 * (lane >> 5) + tq;
-    const unsigned char* arow[2];
+    const unsigned char* arow[NA];
     const unsigned char* brow[NC];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-        arow[a] = A_KM ? AT + tn_kmaj_off<AXW>(tk, 2 * (wm * 64 + a * 32 + tcol))
-                       : AT + (size_t)(wm * 64 + a * 32 + i32) * TN_ROWB + kgrp * 16;
+    for (int a = 0; a < NA; ++a)
+        arow[a] = A_KM ? AT + tn_kmaj_off<AXW>(tk, 2 * (wm * WMR + a * 32 + tcol))
+                       : AT + (size_t)(wm * WMR + a * 32 + i32) * TN_ROWB + kgrp * 16;
 #pragma unroll
     for (int c = 0; c < NC; ++c) brow[c] = BT + tn_kmaj_off<BXW>(tk, 2 * (wn * 32 * NC + c * 32 + tcol));
     fetch(k_begin);
@@ -179,11 +182,11 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
         if (k0 + TN_BK < k_end) fetch(k0 + TN_BK);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 af[2][3], bf[NC][3];
+            bf16x8 af[NA][3], bf[NC][3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < NA; ++a)
                     af[a][p] = A_KM ? tn_tr_fragment<AXW>(arow[a] + p * APLANE + s * 16 * AXW)
                                     : __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(arow[a] + (size_t)p * APLANE + s * 32));
 #pragma unroll
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
 #pragma unroll
             for (int t6 = 0; t6 < 6; ++t6)
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < NA; ++a)
 #pragma unroll
                     for (int c = 0; c < NC; ++c)
                         acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA[t6]], bf[c][PB[t6]], acc[a][c], 0, 0, 0);
@@ -201,14 +204,14 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16x6_kernel(TnJobs jobs, int M,
     }
     float* out = jobs.slab[j] + (size_t)blockIdx.y * jobs.slab_stride[j];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int n = n0 + wn * 32 * NC + c * 32 + i32;
             if (n >= N) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
+                const int m = m0 + wm * WMR + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
                 if (m < M) {
                     float v = acc[a][c][r];
                     if (jobs.drop_p > 0.0f) v = tn_dropout_keep(jobs.drop_seed, (size_t)m * N + n, jobs.drop_p) ? v * (1.0f / (1.0f - jobs.drop_p)) : 0.0f;

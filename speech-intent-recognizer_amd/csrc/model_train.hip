@@ -30,7 +30,7 @@ enum TrainBuf {
 
 // K splits of the four-job bf16x6 weight-gradient launch of one GRU layer (gemm_tn_bf16x6_kernel) and its slab floats
 static inline void tn_x6_plan(int tokens, int in_sz, int* tiles, int* kchunk, int* nsplit, size_t* slab_floats) {
-    const int t = 2 * ((768 / TN_BM) * ((in_sz + TN_BN - 1) / TN_BN) + (768 / TN_BM) * 1);
+    const int t = 2 * ((768 / TN_BM_DW) * ((in_sz + TN_BN - 1) / TN_BN) + (768 / TN_BM_DW) * 1);
     int ks = 256 / t;
     ks = ks < 1 ? 1 : (ks > 16 ? 16 : ks);
     const int kc = (((tokens + ks - 1) / ks) + TN_BK - 1) / TN_BK * TN_BK;
@@ -409,7 +409,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         {
             // all four weight-gradient GEMMs of the layer (2 directions x {W_ih, W_hh}) in one bf16x6 launch
             if (!h->attr_tn) {
-                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
+                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<true, TN_BM_DW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn_lds_bytes(true, TN_BM_DW)));
                 SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
                 SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES_64));
                 h->attr_tn = true;
@@ -430,7 +430,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             }
             for (int j = 0; j < 4; ++j) {
                 jb.tile0[j] = tiles;
-                tiles += (768 / TN_BM) * ((jb.N[j] + TN_BN - 1) / TN_BN);
+                tiles += (768 / TN_BM_DW) * ((jb.N[j] + TN_BN - 1) / TN_BN);
                 sizes[j] = (size_t)768 * jb.N[j];
             }
             jb.tile0[4] = tiles;
@@ -443,7 +443,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                 jb.slab_stride[j] = sizes[j];
                 pos += sizes[j] * nsplit;
             }
-            hipLaunchKernelGGL(gemm_tn_bf16x6_kernel<true>, dim3(tiles, nsplit), dim3(512), TN_LDS_BYTES, st, jb, 768, M, kchunk, S);
+            hipLaunchKernelGGL((gemm_tn_bf16x6_kernel<true, TN_BM_DW>), dim3(tiles, nsplit), dim3(512), tn_lds_bytes(true, TN_BM_DW), st, jb, 768, M, kchunk, S);
             SlabJobs sj{};
             for (int j = 0; j < 4; ++j) { sj.src[j] = jb.slab[j]; sj.out[j] = outs[j]; sj.n[j] = sizes[j]; }
             hipLaunchKernelGGL(slab_reduce_jobs_kernel, dim3(grid_for(sizes[0]), 4), dim3(256), 0, st, sj, nsplit);
