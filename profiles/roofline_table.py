@@ -52,6 +52,10 @@ ROWS = [
     ("gru_quad_kernel<true>", "train GRU recurrence (l0, l1)", "train", "mfma6", F["train_gru_l0"] * B, GI + Y + B * S * 2048 * 4),
     ("gru_bwd_pair_kernel", "BPTT recurrence (l1, l0)", "train", "mfma6", F["bwd_gru_l0"] * B, B * S * (2048 + 512 + 512 + 1536 + 1536) * 4),
     ("gru_bwd_quad_kernel", "BPTT recurrence, MFMA cluster (l1, l0)", "train", "mfma6", F["bwd_gru_l0"] * B, B * S * (2048 + 512 + 512 + 1536 + 1536) * 4),
+    ("gemm_tn2_bf16x6_kernel<true", "GRU dW = dG^T X (l1, l0: mean)", "train", "mfma6", (F["bwd_gru_dw_l0"] + F["bwd_gru_dw_l1"]) * B // 2,
+     (2 * B * S * 1536 * 4 + B * S * (1024 + 512) * 4 // 2 + B * S * 512 * 4)),
+    ("gemm_tn2_bf16x6_kernel<false, 0, 64", "GRU dX l1", "train", "mfma6", F["bwd_gru_dx_l1"] * B, GI + Y),
+    ("gemm_tn2_bf16x6_kernel<false, 0, 128", "GRU dX l0", "train", "mfma6", F["bwd_gru_dx_l0"] * B, GI + X0),
     ("gemm_tn_bf16x6_kernel<true", "GRU dW = dG^T X (l1, l0: mean)", "train", "mfma6", (F["bwd_gru_dw_l0"] + F["bwd_gru_dw_l1"]) * B // 2,
      (2 * B * S * 1536 * 4 + B * S * (1024 + 512) * 4 // 2 + B * S * 512 * 4)),
     ("gemm_tn_bf16x6_kernel<false, 64", "GRU dX l1", "train", "mfma6", F["bwd_gru_dx_l1"] * B, GI + Y),

@@ -39,6 +39,11 @@ int sir_wino2_mask() {
     return m;
 }
 
+int sir_tn2_mask() {
+    static const int m = getenv("SIR_TN2") ? atoi(getenv("SIR_TN2")) : 7;
+    return m;
+}
+
 extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     if (!cfg || !out) { sir_set_error("sir_create: NULL argument"); return SIR_EINVAL; }
     if (cfg->n_fft != SIR_NFFT || cfg->hop_length != SIR_HOP) {

@@ -1,0 +1,224 @@
+// Token-reduction GEMMs of the GRU backward (dW = dG^T X, dX = dG [W; W_reverse]) with SPECIALISED waves: the same tiles, LDS
+// images, transposed fragment reads and epilogue as gemm_tn_bf16x6_kernel (gemm_tn_bf16x6_kernel.h: read that header first), but
+// a BM x 256 x 32 stage is prepared by 8 PRODUCER waves (fp32 loads a whole stage ahead into a second register set, three-way
+// bf16 split, ds_write_b64 into stage buffer s & 1) while 8 CONSUMER waves multiply stage s - 1 from the other buffer: one bare
+// s_barrier per stage, 1024 threads, one workgroup per CU.  In the first kernel all 8 waves do both with two barriers per stage, and
+// the split sits between the MFMA phases (matrix pipe 35-39 % busy, profiles/r03/roofline.md).  The recipe is the producer /
+// consumer Winograd kernel's (conv_wino2_bf16x6_kernel.h): a role's registers are live only in its own branch, the wave index is a
+// scalar, the barrier does not drain vmcnt.  What the knock-outs (template parameter dbg: 1 = no split / LDS stores, 2 = no
+// loads, 16 = idle consumers) showed on the way, B = 256 layer-0 dX, first kernel 140 us:
+//   * 4 producer waves, loads under per-lane bounds branches: 171 us -- the compiler cannot count loads issued under branches and
+//     waits for vmcnt(0) before every use, draining the next stage's loads too;
+//   * branch-free loads a stage ahead (vmcnt(22) .. vmcnt(12) in the ISA): 156 us, producers alone 77 us = 1.6 us per stage for
+//     580 instructions: ONE wave per SIMD issues an instruction every ~6 cycles and that, not the VALU, was the producers' limit;
+//   * 8 producer waves (two per SIMD, half the items each): 120 us; producers alone 61, consumers alone 88 us (MFMA 73 % busy).
+// Measured in the training step (profiles/r03): dX l0 140 -> 120 us, dX l1 (64-row tiles) 100 -> 84, dW 114 -> 110 (mean of layers).
+#pragma once
+#include "gemm_tn_bf16x6_kernel.h"
+
+constexpr int TN2_NPW = 8;                                   // producer waves (two per SIMD: one wave issues too slowly, see below)
+constexpr int TN2_THREADS = 64 * (TN2_NPW + 8);              // + 8 consumer waves
+constexpr int TN2_BM = 128;
+constexpr size_t tn2_lds_bytes(bool a_km, int bm = TN2_BM) { return 2 * tn_lds_bytes(a_km, bm); }     // two stage buffers: 147,456 / 159,744 B (BM = 128)
+
+__device__ __forceinline__ void tn2_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool A_KM, int dbg = 0, int BM = TN2_BM>
+__global__ __launch_bounds__(TN2_THREADS, TN2_THREADS / 256) void gemm_tn2_bf16x6_kernel(TnJobs jobs, int M, int K, int kchunk, int seq) {
+    constexpr int NC = BM >= 128 ? 2 : 1;                    // BM = 128: consumers 2 x 4, wave tile 64 x 64; BM = 64: 1 x 8, wave tile 64 x 32
+    constexpr int AXW = BM * 2, BXW = TN_BN * 2;             // row bytes of the k-major images
+    constexpr int APLANE = A_KM ? TN_BK * AXW : BM * TN_ROWB, BPLANE = TN_BK * BXW;
+    constexpr int STAGE = 3 * APLANE + 3 * BPLANE;
+    constexpr int NPT = 64 * TN2_NPW;                         // producer threads
+    constexpr int NAQ = BM * 8 / NPT, NBQ = TN_BN * 8 / NPT;  // staging items per PRODUCER thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char tl2[];
+    int j = 0;
+    while (j + 1 < jobs.njobs && (int)blockIdx.x >= jobs.tile0[j + 1]) ++j;
+    const int tile = blockIdx.x - jobs.tile0[j];
+    const int N = jobs.N[j], lda = jobs.lda[j], ldb = jobs.ldb[j], shift = jobs.shift[j];
+    const int ntn = (N + TN_BN - 1) / TN_BN;
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * TN_BN;
+    const float* __restrict__ A = jobs.A[j];
+    const float* __restrict__ B = jobs.B[j];
+    const float* __restrict__ B2 = jobs.B2[j];
+    const int brows = jobs.brows[j];
+    const int k_begin = blockIdx.y * kchunk, k_end = min(K, k_begin + kchunk);
+    const int nst = (k_end - k_begin + TN_BK - 1) / TN_BK;     // stages of this workgroup
+    const int npair = nst / 2 + 1;                            // steps 0 .. nst, rounded up to pairs: 2 * npair barriers in both roles
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    if (wv < TN2_NPW) {
+        // ================= producers ==============================================================================================
+        __builtin_amdgcn_s_setprio((dbg & 64) ? 0 : 3);                       // their VALU stream competes with two MFMA-issuing waves per SIMD
+        const int ptid = tid;                                // 0 .. NPT - 1
+        float4 pa0[NAQ], pb0[NBQ], pa1[NAQ], pb1[NBQ];      // two register sets: the loads of stage s + 1 are issued BEFORE stage s is split
+        // A producer wave issues ONE instruction stream: every instruction of its step counts (~4.3 cycles each, measured: 450
+        // instructions of splitting and LDS stores = 0.8 us), so the fetch is kept to ~15 scalar + 1 vector instruction per item:
+        //  * loads are UNCONDITIONAL and the loop body is branch-free (the steps are rounded up to pairs): under per-lane or per-step
+        //    branches the compiler cannot count the outstanding loads and waits for vmcnt(0) before every use, which drains the NEXT
+        //    stage's loads too;
+        //  * the B row of an item (wave + 4 q) is wave-uniform: row address, the utterance-boundary test of the shifted W_hh
+        //    operand (t = token % seq is carried from stage to stage, not divided out) and the [W; W_reverse] selection stay on the
+        //    scalar unit; a row that must read as zero (past k_end, across an utterance boundary) is loaded from the zero page;
+        //  * rows m >= M of A and columns n >= N of B only feed outputs that are never stored: they read a valid address, nothing
+        //    more; a row of A past k_end is clamped to the last valid one (finite values times the zero row of B).
+        const unsigned ncol = (n0 + 4 * lane < N) ? 4u * lane : 0u;        // column offset inside the tile's 256-column row segment
+        unsigned aoffv[NAQ];                                               // loop-invariant part of the A addresses (elements)
+        int arow[NAQ];                                                     // A_KM: token row of the item inside a stage
+#pragma unroll
+        for (int q = 0; q < NAQ; ++q) {
+            const int it = ptid + NPT * q;
+            if (A_KM) {
+                const int m = m0 + 4 * (it % (BM / 4));
+                arow[q] = it / (BM / 4);
+                aoffv[q] = m < M ? m : 0;
+            } else {
+                const int m = m0 + (it >> 3);
+                arow[q] = 0;
+                aoffv[q] = (unsigned)(m < M ? m : 0) * (unsigned)lda;
+            }
+        }
+        const int akk = 4 * (tid & 7);                                     // !A_KM: k offset of the lane inside a stage
+        const int dmod = shift != 0 ? TN_BK % seq : 0;
+        int tq[NBQ];                                                       // (token of B item q) % seq, carried; scalar
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) tq[q] = shift != 0 ? (k_begin + wv + TN2_NPW * q) % seq : 0;
+        const float* __restrict__ zeros = jobs.zeros;
+        auto fetch = [&](int k0, float4 (&pa)[NAQ], float4 (&pb)[NBQ]) {
+            if (dbg & 32) k0 = k_begin + (k0 & 32);
+            if (A_KM) {
+#pragma unroll
+                for (int q = 0; q < NAQ; ++q) {
+                    const int tok = min(k0 + arow[q], k_end - 1);
+                    pa[q] = *reinterpret_cast<const float4*>(A + ((unsigned)tok * (unsigned)lda + aoffv[q]));
+                }
+            } else {
+                const unsigned kc = k0 + akk < k_end ? k0 + akk : k_end - 4;
+#pragma unroll
+                for (int q = 0; q < NAQ; ++q) pa[q] = *reinterpret_cast<const float4*>(A + (aoffv[q] + kc));
+            }
+#pragma unroll
+            for (int q = 0; q < NBQ; ++q) {
+                const int tok = k0 + wv + TN2_NPW * q;                           // scalar
+                bool ok = tok < k_end;
+                if (shift != 0) {                                          // neighbouring time step of the same utterance
+                    const int t = tq[q] + shift;
+                    ok = ok && t >= 0 && t < seq;
+                    tq[q] += dmod;
+                    tq[q] -= tq[q] >= seq ? seq : 0;
+                }
+                const int src = tok + shift;
+                const float* row = (brows > 0 && src >= brows) ? B2 + (unsigned)(src - brows) * (unsigned)ldb + n0 : B + (unsigned)src * (unsigned)ldb + n0;
+                pb[q] = *reinterpret_cast<const float4*>((ok ? row : zeros) + ncol);
+            }
+        };
+        auto stage = [&](unsigned char* AT, unsigned char* BT, const float4 (&pa)[NAQ], const float4 (&pb)[NBQ]) {
+#pragma unroll
+            for (int q = 0; q < NAQ; ++q) {
+                const int it = ptid + NPT * q;
+                uint2 hh, mm, ll;
+                split3_quad(pa[q], hh, mm, ll);
+                unsigned char* d = A_KM ? AT + tn_kmaj_off<AXW>(it / (BM / 4), 8 * (it % (BM / 4)))
+                                        : AT + (size_t)(it >> 3) * TN_ROWB + (it & 7) * 8;
+                *reinterpret_cast<uint2*>(d) = hh;
+                *reinterpret_cast<uint2*>(d + APLANE) = mm;
+                *reinterpret_cast<uint2*>(d + 2 * APLANE) = ll;
+            }
+#pragma unroll
+            for (int q = 0; q < NBQ; ++q) {
+                const int it = ptid + NPT * q;
+                uint2 hh, mm, ll;
+                split3_quad(pb[q], hh, mm, ll);
+                unsigned char* d = BT + tn_kmaj_off<BXW>(it >> 6, 8 * (it & 63));
+                *reinterpret_cast<uint2*>(d) = hh;
+                *reinterpret_cast<uint2*>(d + BPLANE) = mm;
+                *reinterpret_cast<uint2*>(d + 2 * BPLANE) = ll;
+            }
+        };
+        fetch(k_begin, pa0, pb0);
+#pragma unroll 1
+        for (int s = 0; s < 2 * npair; s += 2) {
+            if (!(dbg & 2)) fetch(k_begin + (s + 1) * TN_BK, pa1, pb1);     // a whole step ahead, in flight across the barrier
+            if (!(dbg & 1)) stage(tl2, tl2 + 3 * APLANE, pa0, pb0);         // (past the last stage: zeros into the idle buffer)
+            tn2_barrier();
+            if (!(dbg & 2)) fetch(k_begin + (s + 2) * TN_BK, pa0, pb0);
+            if (!(dbg & 1)) stage(tl2 + STAGE, tl2 + STAGE + 3 * APLANE, pa1, pb1);
+            tn2_barrier();
+        }
+        return;
+    }
+
+    // ================= consumers ==================================================================================================
+    if (dbg & 64) __builtin_amdgcn_s_setprio(2);
+    const int cw = wv - TN2_NPW, wm = BM >= 128 ? cw >> 2 : 0, wn = BM >= 128 ? cw & 3 : cw, i32 = lane & 31, kgrp = lane >> 5;
+    f32x16 acc[2][NC];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
+    // fragment addresses inside a stage buffer (see gemm_tn_bf16x6_kernel: transposed reads of the k-major images)
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tcol = 16 * ((lane >> 4) & 1) + 4 * tp, tk = 8 * (lane >> 5) + tq;
+    int aoff[2], boff[NC];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+        aoff[a] = A_KM ? tn_kmaj_off<AXW>(tk, 2 * (wm * 64 + a * 32 + tcol)) : (wm * 64 + a * 32 + i32) * TN_ROWB + kgrp * 16;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) boff[c] = 3 * APLANE + tn_kmaj_off<BXW>(tk, 2 * (wn * 32 * NC + c * 32 + tcol));
+    tn2_barrier();                                           // step 0: the producers write stage 0
+#pragma unroll 1
+    for (int s = 1; s <= nst; ++s) {
+        const unsigned char* sb = tl2 + (((dbg & 8) ? 0 : (s - 1)) & 1) * STAGE;
+        if (dbg & 16) { tn2_barrier(); continue; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2][3], bf[NC][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    af[a][p] = A_KM ? tn_tr_fragment<AXW>(sb + aoff[a] + p * APLANE + ks * 16 * AXW)
+                                    : __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + aoff[a] + p * APLANE + ks * 32));
+#pragma unroll
+                for (int c = 0; c < NC; ++c) bf[c][p] = tn_tr_fragment<BXW>(sb + boff[c] + p * BPLANE + ks * 16 * BXW);
+            }
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
+            if (dbg & 4) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) { acc[a][c][p] += (float)af[a][p][0]; acc[a][c][p + 3] += (float)bf[c][p][1]; }
+                continue;
+            }
+#pragma unroll
+            for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA[t6]], bf[c][PB[t6]], acc[a][c], 0, 0, 0);
+        }
+        tn2_barrier();
+    }
+    if (!(nst & 1)) tn2_barrier();                           // the odd step of the producers' last pair
+    float* out = jobs.slab[j] + (size_t)blockIdx.y * jobs.slab_stride[j];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int n = n0 + wn * 32 * NC + c * 32 + i32;
+            if (n >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
+                if (m < M) {
+                    float v = acc[a][c][r];
+                    if (jobs.drop_p > 0.0f) v = tn_dropout_keep(jobs.drop_seed, (size_t)m * N + n, jobs.drop_p) ? v * (1.0f / (1.0f - jobs.drop_p)) : 0.0f;
+                    out[(size_t)m * N + n] = v;
+                }
+            }
+        }
+}

@@ -66,6 +66,7 @@ struct TnJobs {
     int njobs;
     float drop_p;                                            // > 0: out[m][n] *= keep(drop_seed, m * N + n) / (1 - drop_p)
     unsigned long long drop_seed;
+    const float* zeros;                                      // >= 256 zero floats (the handle's zero page): B rows that must read as zero (gemm_tn2)
 };
 
 // A_KM = true : A is [K][lda] (m contiguous: dW = dG^T X), staged transposed like B.

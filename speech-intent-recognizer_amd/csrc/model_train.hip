@@ -7,6 +7,7 @@
 #include "conv_wino2_bf16x6_kernel.h"
 #include "wgrad_bf16x6_kernel.h"
 #include "gemm_tn_bf16x6_kernel.h"
+#include "gemm_tn2_bf16x6_kernel.h"
 
 namespace {
 
@@ -30,7 +31,8 @@ enum TrainBuf {
 
 // K splits of the four-job bf16x6 weight-gradient launch of one GRU layer (gemm_tn_bf16x6_kernel) and its slab floats
 static inline void tn_x6_plan(int tokens, int in_sz, int* tiles, int* kchunk, int* nsplit, size_t* slab_floats) {
-    const int t = 2 * ((768 / TN_BM_DW) * ((in_sz + TN_BN - 1) / TN_BN) + (768 / TN_BM_DW) * 1);
+    const int bm = (sir_tn2_mask() & 1) ? TN2_BM : TN_BM_DW;
+    const int t = 2 * ((768 / bm) * ((in_sz + TN_BN - 1) / TN_BN) + (768 / bm) * 1);
     int ks = 256 / t;
     ks = ks < 1 ? 1 : (ks > 16 ? 16 : ks);
     const int kc = (((tokens + ks - 1) / ks) + TN_BK - 1) / TN_BK * TN_BK;
@@ -412,12 +414,17 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                 SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<true, TN_BM_DW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn_lds_bytes(true, TN_BM_DW)));
                 SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
                 SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES_64));
+                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn2_bf16x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn2_lds_bytes(true)));
+                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn2_bf16x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn2_lds_bytes(false)));
+                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn2_bf16x6_kernel<false, 0, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn2_lds_bytes(false, 64)));
                 h->attr_tn = true;
             }
+            const bool tn2_dw = sir_tn2_mask() & 1;
             TnJobs jb{};
             float* outs[4];
             size_t sizes[4];
             jb.njobs = 4;
+            jb.zeros = h->zero_page;
             int tiles = 0;
             for (int dir = 0; dir < 2; ++dir) {
                 const int gi_idx = 2 * layer + dir;
@@ -430,7 +437,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             }
             for (int j = 0; j < 4; ++j) {
                 jb.tile0[j] = tiles;
-                tiles += (768 / TN_BM_DW) * ((jb.N[j] + TN_BN - 1) / TN_BN);
+                tiles += (768 / (tn2_dw ? TN2_BM : TN_BM_DW)) * ((jb.N[j] + TN_BN - 1) / TN_BN);
                 sizes[j] = (size_t)768 * jb.N[j];
             }
             jb.tile0[4] = tiles;
@@ -443,7 +450,10 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                 jb.slab_stride[j] = sizes[j];
                 pos += sizes[j] * nsplit;
             }
-            hipLaunchKernelGGL((gemm_tn_bf16x6_kernel<true, TN_BM_DW>), dim3(tiles, nsplit), dim3(512), tn_lds_bytes(true, TN_BM_DW), st, jb, 768, M, kchunk, S);
+            if (tn2_dw)
+                hipLaunchKernelGGL(gemm_tn2_bf16x6_kernel<true>, dim3(tiles, nsplit), dim3(TN2_THREADS), tn2_lds_bytes(true), st, jb, 768, M, kchunk, S);
+            else
+                hipLaunchKernelGGL((gemm_tn_bf16x6_kernel<true, TN_BM_DW>), dim3(tiles, nsplit), dim3(512), tn_lds_bytes(true, TN_BM_DW), st, jb, 768, M, kchunk, S);
             SlabJobs sj{};
             for (int j = 0; j < 4; ++j) { sj.src[j] = jb.slab[j]; sj.out[j] = outs[j]; sj.n[j] = sizes[j]; }
             hipLaunchKernelGGL(slab_reduce_jobs_kernel, dim3(grid_for(sizes[0]), 4), dim3(256), 0, st, sj, nsplit);
@@ -455,6 +465,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         {
             TnJobs jn{};
             jn.njobs = 1;
+            jn.zeros = h->zero_page;
             if (layer == 1 && dropout_p > 0.0f) { jn.drop_p = dropout_p; jn.drop_seed = dropout_seed; }   // dy0 = mask * d(y0d)
             jn.A[0] = p.dgi; jn.lda[0] = 1536;
             jn.B[0] = w->gru_w_ih[2 * layer]; jn.B2[0] = w->gru_w_ih[2 * layer + 1]; jn.brows[0] = 768; jn.ldb[0] = in_sz;
@@ -466,10 +477,16 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             if (ntiles < 160) {                              // too few 128-row tiles to fill the CUs: 64-row tiles
                 ntiles = ((M + 63) / 64) * ntn;
                 jn.tile0[1] = ntiles;
-                hipLaunchKernelGGL((gemm_tn_bf16x6_kernel<false, 64>), dim3(ntiles, 1), dim3(512), TN_LDS_BYTES_64, st, jn, M, 1536, 1536, 1);
+                if (sir_tn2_mask() & 4)
+                    hipLaunchKernelGGL((gemm_tn2_bf16x6_kernel<false, 0, 64>), dim3(ntiles, 1), dim3(TN2_THREADS), tn2_lds_bytes(false, 64), st, jn, M, 1536, 1536, 1);
+                else
+                    hipLaunchKernelGGL((gemm_tn_bf16x6_kernel<false, 64>), dim3(ntiles, 1), dim3(512), TN_LDS_BYTES_64, st, jn, M, 1536, 1536, 1);
             } else {
                 jn.tile0[1] = ntiles;
-                hipLaunchKernelGGL(gemm_tn_bf16x6_kernel<false>, dim3(ntiles, 1), dim3(512), TN_LDS_BYTES, st, jn, M, 1536, 1536, 1);
+                if (sir_tn2_mask() & 2)
+                    hipLaunchKernelGGL(gemm_tn2_bf16x6_kernel<false>, dim3(ntiles, 1), dim3(TN2_THREADS), tn2_lds_bytes(false), st, jn, M, 1536, 1536, 1);
+                else
+                    hipLaunchKernelGGL(gemm_tn_bf16x6_kernel<false>, dim3(ntiles, 1), dim3(512), TN_LDS_BYTES, st, jn, M, 1536, 1536, 1);
             }
         }
         KCHECK();
