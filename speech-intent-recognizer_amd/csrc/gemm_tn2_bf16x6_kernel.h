@@ -12,6 +12,11 @@
 //   * branch-free loads a stage ahead (vmcnt(22) .. vmcnt(12) in the ISA): 156 us, producers alone 77 us = 1.6 us per stage for
 //     580 instructions: ONE wave per SIMD issues an instruction every ~6 cycles and that, not the VALU, was the producers' limit;
 //   * 8 producer waves (two per SIMD, half the items each): 120 us; producers alone 61, consumers alone 88 us (MFMA 73 % busy).
+//   * tried and removed: the B operand of dX (the weights) taken from the forward GEMM's bf16x3 planes by LDS-DMA with the chunk
+//     swizzle on the source address -- no split, no LDS stores, 4 producer waves.  Parity-correct, slower: 139 us (consumers alone
+//     88, producers alone 73, without the DMA 97, without the A operand 116).  6 bytes per element instead of 4 come through L2, and
+//     whatever the producers do -- VALU or DMA -- ADDS to the consumers' time instead of hiding behind it: with the matrix pipe this
+//     busy the step runs at the board's power limit, so energy per stage, not issue slots, is what counts.
 // Measured in the training step (profiles/r03): dX l0 140 -> 120 us, dX l1 (64-row tiles) 100 -> 84, dW 114 -> 110 (mean of layers).
 #pragma once
 #include "gemm_tn_bf16x6_kernel.h"
