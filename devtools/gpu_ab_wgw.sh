@@ -1,0 +1,16 @@
+#!/bin/bash
+# A/B of the convolution weight gradients inside the training step: Winograd form (SIR_WGW = 3, the default) against the nine-tap
+# kernel (SIR_WGW = 0); per-kernel durations from rocprofv3's kernel trace (run via gpurun)
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+for m in ${MASKS:-0 3}; do
+SIR_WGW=$m timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_wgw -o wgw_m$m -- python3 $R/bench.py --steps 2 --warmup 1 --repeats 1 --train-steps 20 --no-cpu-baseline --no-dist-leg --no-augment --no-host-feed --sustain-seconds 0 --streams 1 > $R/gpurun_out/wgw_m$m.log 2>&1 || { tail -20 $R/gpurun_out/wgw_m$m.log; exit 1; }
+echo "SIR_WGW=$m"; python3 -c "
+import csv,sys,json
+for r in csv.reader(open(sys.argv[1])):
+    if 'wgrad' in r[0]: print('   ', r[0][:60], r[1], 'avg', round(float(r[3])/1000,1), 'min', round(float(r[5])/1000,1), 'max', round(float(r[6])/1000,1))
+pass
+" $R/gpurun_out/prof_wgw/wgw_m${m}_kernel_stats.csv $R/gpurun_out/wgw_m$m.log
+done

@@ -39,6 +39,11 @@ int sir_wino2_mask() {
     return m;
 }
 
+int sir_wgw_mask() {
+    static const int m = getenv("SIR_WGW") ? atoi(getenv("SIR_WGW")) : 3;
+    return m;
+}
+
 int sir_tn2_mask() {
     static const int m = getenv("SIR_TN2") ? atoi(getenv("SIR_TN2")) : 7;
     return m;

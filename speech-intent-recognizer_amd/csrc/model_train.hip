@@ -8,6 +8,7 @@
 #include "wgrad_bf16x6_kernel.h"
 #include "gemm_tn_bf16x6_kernel.h"
 #include "gemm_tn2_bf16x6_kernel.h"
+#include "wgrad_wino_bf16x6_kernel.h"
 
 namespace {
 
@@ -116,7 +117,8 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
         tn_x6_plan(d.B * d.S, in_sz, &t_, &kc_, &ns_, &need);
         if (need > slab) slab = need;
     }
-    n[TB_SLAB] = slab + (size_t)WGR_PARTS * 9 * 128 * 64;       // + the partial sums of the two-pass wgrad reduce
+    if ((size_t)WGW_MAX_STRIPS * 16 * 128 * 64 > slab) slab = (size_t)WGW_MAX_STRIPS * 16 * 128 * 64;      // Winograd weight-gradient slabs
+    n[TB_SLAB] = slab + (size_t)WGR_PARTS * 16 * 128 * 64;      // + the partial sums of the two-pass wgrad reduce
     n[TB_XS] = (B * S * 1024 * 3 + 1) / 2;                       // ushort count / 2 (sizes are in floats)
     n[TB_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512 + 1) / 2;
     // conv2 forward and the conv3 data gradient in Winograd form (16 frequencies), conv3 forward and the conv2 data gradient direct (9 taps)
@@ -498,6 +500,8 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
     if (!h->attr_wgrad) {
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<64, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_wino_bf16x6_kernel<64, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgwCfg<64, 128>::lds_bytes));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_wino_bf16x6_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgwCfg<32, 64>::lds_bytes));
         h->attr_wgrad = true;
     }
     {
@@ -517,6 +521,17 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         }
         {
             SirProfScope prof(h, SIR_K_B_WGRAD3, st);
+            if (sir_wgw_mask() & 2) {
+                // Winograd form: 16 products per tile and channel pair instead of 36 (wgrad_wino_bf16x6_kernel.h)
+                using Cfg3 = WgwCfg<64, 128>;
+                const int strips = wgrad_wino_strips(B, 16, d.wp2, Cfg3::TPS);
+                hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<64, 128>), dim3(4 * strips), dim3(WGW_THREADS), Cfg3::lds_bytes, st,
+                                   (const float*)p.dz3, (const float*)p.a2, p.slab, (const float*)h->zero_page, B, 16, d.wp2);
+                float* part = p.slab + (size_t)strips * 16 * 128 * 64;
+                hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((16 * 128 * 64 / 4 + 255) / 256), dim3(256), 0, st, (const float*)p.slab, strips,
+                                   16 * 128 * 64 / 4, part);
+                hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((128 * 64 + 255) / 256), dim3(256), 0, st, (const float*)part, 64, 128, g->conv_w[2]);
+            } else {
             const size_t ldsx = wgrad_x6_lds_bytes(64, 128, d.wp2);
             if (ldsx > 160 * 1024 || d.wp2 > wgrad_x6_max_w(128)) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
             const int nslab3 = d.wg3_blocks;                  // one slab per workgroup
@@ -527,6 +542,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                                (const float*)p.slab, nslab3, 9 * 128 * 64 / 4, part);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 128 * 64 + 255) / 256), dim3(256), 0, st, (const float*)part, WGR_PARTS, 64, 128,
                                g->conv_w[2]);
+            }
         }
         {
             // data gradient = a 128 -> 64 convolution with the flipped / transposed taps: the Winograd kernel (16 of 36 products), blocks
@@ -561,6 +577,16 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         }
         {
             SirProfScope prof(h, SIR_K_B_WGRAD2, st);
+            if (sir_wgw_mask() & 1) {
+                using Cfg2 = WgwCfg<32, 64>;
+                const int strips = wgrad_wino_strips(B, 32, d.wp1, Cfg2::TPS);
+                hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<32, 64>), dim3(4 * strips), dim3(WGW_THREADS), Cfg2::lds_bytes, st,
+                                   (const float*)p.dz2, (const float*)p.a1, p.slab, (const float*)h->zero_page, B, 32, d.wp1);
+                float* part = p.slab + (size_t)strips * 16 * 64 * 32;
+                hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((16 * 64 * 32 / 4 + 255) / 256), dim3(256), 0, st, (const float*)p.slab, strips,
+                                   16 * 64 * 32 / 4, part);
+                hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((64 * 32 + 255) / 256), dim3(256), 0, st, (const float*)part, 32, 64, g->conv_w[1]);
+            } else {
             const size_t ldsx = wgrad_x6_lds_bytes(32, 64, d.wp1);
             if (ldsx > 160 * 1024 || d.wp1 > wgrad_x6_max_w(64)) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
             const int nslab2 = d.wg2_blocks;                  // one slab per workgroup (its four k-split waves add up in LDS)
@@ -571,6 +597,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                                (const float*)p.slab, nslab2, 9 * 64 * 32 / 4, part);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 32 + 255) / 256), dim3(256), 0, st, (const float*)part, WGR_PARTS, 32, 64,
                                g->conv_w[1]);
+            }
         }
         {
             SirProfScope prof(h, SIR_K_B_DGRAD2, st);
