@@ -73,7 +73,8 @@ FLOPS_PER_UTT = {
 }
 BF16X6_KERNELS = {k for k in FLOPS_PER_UTT if "conv1" not in k}
 # csrc/conv_wino2_bf16x6_kernel.h (producer / consumer Winograd kernel; SIR_WINO2 selects the stages, default all three)
-WINOGRAD_KERNELS = {"conv2_mfma_bn_relu_pool", "conv3_mfma_bn_relu_pool", "train_conv2_fwd", "train_conv3_fwd", "bwd_conv3_dgrad"}
+WINOGRAD_KERNELS = {"conv2_mfma_bn_relu_pool", "conv3_mfma_bn_relu_pool", "train_conv2_fwd", "train_conv3_fwd", "bwd_conv3_dgrad",
+                    "bwd_conv2_wgrad", "bwd_conv3_wgrad"}
 FWD_FLOPS_PER_UTT = 400646144
 TRAIN_FLOPS_PER_UTT = 3 * FWD_FLOPS_PER_UTT                  # fwd + dgrad + wgrad convention: 1 201 938 432
 FEATURE_BYTES_PER_UTT = CLIP_LEN * 4 + 64 * T_PAD * 4       # 243 200 B (fp32 waveform in, features out)

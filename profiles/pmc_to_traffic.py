@@ -25,6 +25,7 @@ NAME_MAP = [
     ("conv3x3_wino_bf16x6_kernel<128, 64", "bwd_conv3_dgrad"),
     ("conv3x3_wino_bf16x6_kernel<32, 64, 2", "train_conv2_fwd"), ("conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 2", "train_conv3_fwd"),
     ("conv3x3_bf16x6_ns_kernel<64, 32", "bwd_conv2_dgrad"), ("conv3x3_bf16x6_ns_kernel<128, 64", "bwd_conv3_dgrad"),
+    ("conv_wgrad_wino_bf16x6_kernel<32, 64>", "bwd_conv2_wgrad"), ("conv_wgrad_wino_bf16x6_kernel<64, 128>", "bwd_conv3_wgrad"),
     ("conv_wgrad_bf16x6_kernel<32, 64>", "bwd_conv2_wgrad"), ("conv_wgrad_bf16x6_kernel<64, 128>", "bwd_conv3_wgrad"),
     ("gru_quad_kernel<true>", "train_gru"), ("gru_bwd_pair_kernel", "bwd_gru"),
     ("gemm_tn2_bf16x6_kernel<true", "bwd_gru_dw"), ("gemm_tn2_bf16x6_kernel<false", "bwd_gru_dx"),

@@ -117,7 +117,7 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
         tn_x6_plan(d.B * d.S, in_sz, &t_, &kc_, &ns_, &need);
         if (need > slab) slab = need;
     }
-    if ((size_t)WGW_MAX_STRIPS * 16 * 128 * 64 > slab) slab = (size_t)WGW_MAX_STRIPS * 16 * 128 * 64;      // Winograd weight-gradient slabs
+    if ((size_t)64 * 16 * 128 * 64 > slab) slab = (size_t)64 * 16 * 128 * 64;      // Winograd weight-gradient slabs: 64 strips of conv3, 128 of conv2
     n[TB_SLAB] = slab + (size_t)WGR_PARTS * 16 * 128 * 64;      // + the partial sums of the two-pass wgrad reduce
     n[TB_XS] = (B * S * 1024 * 3 + 1) / 2;                       // ushort count / 2 (sizes are in floats)
     n[TB_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512 + 1) / 2;
@@ -524,9 +524,9 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             if (sir_wgw_mask() & 2) {
                 // Winograd form: 16 products per tile and channel pair instead of 36 (wgrad_wino_bf16x6_kernel.h)
                 using Cfg3 = WgwCfg<64, 128>;
-                const int strips = wgrad_wino_strips(B, 16, d.wp2, Cfg3::TPS);
-                hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<64, 128>), dim3(4 * strips), dim3(WGW_THREADS), Cfg3::lds_bytes, st,
-                                   (const float*)p.dz3, (const float*)p.a2, p.slab, (const float*)h->zero_page, B, 16, d.wp2);
+                const int strips = wgrad_wino_strips(B, 16, d.wp2, Cfg3::TPS, Cfg3::groups);
+                hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<64, 128>), dim3(Cfg3::groups * strips), dim3(WGW_THREADS), Cfg3::lds_bytes, st,
+                                   (const float*)p.dz3, (const float*)p.a2, p.slab, B, 16, d.wp2);
                 float* part = p.slab + (size_t)strips * 16 * 128 * 64;
                 hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((16 * 128 * 64 / 4 + 255) / 256), dim3(256), 0, st, (const float*)p.slab, strips,
                                    16 * 128 * 64 / 4, part);
@@ -579,9 +579,9 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             SirProfScope prof(h, SIR_K_B_WGRAD2, st);
             if (sir_wgw_mask() & 1) {
                 using Cfg2 = WgwCfg<32, 64>;
-                const int strips = wgrad_wino_strips(B, 32, d.wp1, Cfg2::TPS);
-                hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<32, 64>), dim3(4 * strips), dim3(WGW_THREADS), Cfg2::lds_bytes, st,
-                                   (const float*)p.dz2, (const float*)p.a1, p.slab, (const float*)h->zero_page, B, 32, d.wp1);
+                const int strips = wgrad_wino_strips(B, 32, d.wp1, Cfg2::TPS, Cfg2::groups);
+                hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<32, 64>), dim3(Cfg2::groups * strips), dim3(WGW_THREADS), Cfg2::lds_bytes, st,
+                                   (const float*)p.dz2, (const float*)p.a1, p.slab, B, 32, d.wp1);
                 float* part = p.slab + (size_t)strips * 16 * 64 * 32;
                 hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((16 * 64 * 32 / 4 + 255) / 256), dim3(256), 0, st, (const float*)p.slab, strips,
                                    16 * 64 * 32 / 4, part);

@@ -22,17 +22,23 @@
 #include "gemm_tn2_bf16x6_kernel.h"
 
 constexpr int WGW_THREADS = 1024;
-constexpr int WGW_MAX_STRIPS = 64;
+// KPW = rows of the frequency grid per workgroup: 1 for 64 -> 128 (4 frequencies x 128 x 64 accumulators fill the consumers' registers),
+// 2 for 32 -> 64 (8 x 64 x 32: a quarter of that) -- the dY rows are then loaded once for two rows and the input patch needs 3 rows
+// for two instead of 2 for one: 0.6x the bytes per tile and row, and the 32 -> 64 kernel is bound by what a CU can pull in.
 template <int CIN, int COUT> struct WgwCfg {
-    static constexpr int TPS = COUT >= 128 ? 16 : 32;                     // tiles per stage (K of one or two MFMA steps)
+    static constexpr int KPW = COUT >= 128 ? 1 : 2;
+    static constexpr int NF = 4 * KPW;                                    // frequencies per workgroup
+    static constexpr int TPS = 16;                                        // tiles per stage (K of one MFMA step)
     static constexpr int ZW = COUT * 2, AW = CIN * 2;                     // row bytes of the P / V images (one plane)
     static constexpr int PPLANE = TPS * ZW, VPLANE = TPS * AW;
-    static constexpr int STAGE = 4 * 3 * (PPLANE + VPLANE);               // 4 frequencies x 3 planes
+    static constexpr int STAGE = NF * 3 * (PPLANE + VPLANE);
     static constexpr size_t lds_bytes = 2 * (size_t)STAGE;                // 147,456 B for both shapes
+    static constexpr int groups = 4 / KPW;                                // workgroups per strip
 };
-inline int wgrad_wino_strips(int B, int H, int W, int tps) {
+inline int wgrad_wino_strips(int B, int H, int W, int tps, int groups) {
     const long long ntiles = (long long)B * (H / 2) * ((W + 1) / 2), nst = (ntiles + tps - 1) / tps;
-    int s = nst < WGW_MAX_STRIPS ? (int)nst : WGW_MAX_STRIPS;
+    const int cap = 256 / groups;                                           // one workgroup per CU
+    int s = nst < cap ? (int)nst : cap;
     if (s >= 8) s &= ~7;                                                    // multiples of 8: the XCD-aware order below
     return s < 1 ? 1 : s;
 }
@@ -50,21 +56,25 @@ __device__ __forceinline__ float4 wgw_neg(const float4& x) { return make_float4(
 // dz: [B][H][W][COUT] (gradient of the raw conv output), a: [B][H][W][CIN] (the layer input), slab: [strips][4 i][4 j][COUT][CIN]
 template <int CIN, int COUT>
 __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_wino_bf16x6_kernel(
-    const float* __restrict__ dz, const float* __restrict__ a, float* __restrict__ slab, const float* __restrict__ zeros, int B, int H, int W) {
+    const float* __restrict__ dz, const float* __restrict__ a, float* __restrict__ slab, int B, int H, int W) {
     using C = WgwCfg<CIN, COUT>;
-    constexpr int TPS = C::TPS, ZW = C::ZW, AW = C::AW, PPLANE = C::PPLANE, VPLANE = C::VPLANE, STAGE = C::STAGE;
-    constexpr int MT2 = COUT / 64, NT = CIN / 32;               // 32 x 32 accumulators per consumer wave: MT2 x NT (half of the co tiles, all ci tiles)
+    constexpr int KPW = C::KPW, NF = C::NF, TPS = C::TPS, ZW = C::ZW, AW = C::AW, PPLANE = C::PPLANE, VPLANE = C::VPLANE, STAGE = C::STAGE;
+    constexpr int WPF = 8 / NF;                                 // consumer waves per frequency (2 or 1)
+    constexpr int MTW = COUT / 32 / WPF, NT = CIN / 32;         // 32 x 32 accumulators per consumer wave: MTW x NT
     constexpr int PQ = COUT / 4, VQ = CIN / 4;                  // channel quads per tile
-    static_assert(TPS * PQ == 512 && TPS * VQ == 256, "one dY item per producer thread, one input item per thread of waves 0-3");
+    // producer items: KPW = 1: a dY item (4 loads -> 4 frequencies) on every thread, an input item (8 loads -> 4) on waves 0-3;
+    //                 KPW = 2: a dY item (4 loads -> 8 frequencies) on waves 0-3, an input item of ONE row (8 loads -> 4) on waves 4-7
+    static_assert(TPS * PQ == (KPW == 1 ? 512 : 256) && TPS * VQ * KPW == 256, "item counts");
     extern __shared__ __attribute__((aligned(16))) unsigned char wgl[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int TH = H >> 1, TW = (W + 1) >> 1;
     const int ntiles = B * TH * TW, nstages = (ntiles + TPS - 1) / TPS;
-    // blockIdx -> (strip, kind): the four kinds of a strip on one XCD (workgroup L runs on XCD L % 8) when the strips come in eights
-    const int nstrips = gridDim.x >> 2;
-    int strip, kind;
-    if ((nstrips & 7) == 0) { strip = (blockIdx.x & 7) + 8 * (blockIdx.x >> 5); kind = (blockIdx.x >> 3) & 3; }
-    else { strip = blockIdx.x >> 2; kind = blockIdx.x & 3; }
+    // blockIdx -> (strip, group of rows): the groups of a strip on one XCD (workgroup L runs on XCD L % 8) when the strips come in eights
+    constexpr int NG = C::groups;
+    const int nstrips = gridDim.x / NG;
+    int strip, grp;
+    if ((nstrips & 7) == 0) { strip = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * NG)); grp = (blockIdx.x >> 3) % NG; }
+    else { strip = blockIdx.x / NG; grp = blockIdx.x % NG; }
     const int s_begin = (int)((long long)nstages * strip / nstrips), s_end = (int)((long long)nstages * (strip + 1) / nstrips);
     const int nst = s_end - s_begin;
 
@@ -72,12 +82,15 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
         // ================= producers ==============================================================================================
         __builtin_amdgcn_s_setprio(3);
         // row i of A (4 x 2): (1,0), (1,1), (1,-1), (0,-1); row i of B^T (4 x 4): d0 - d2, d1 + d2, d2 - d1, d1 - d3
-        const float alpha = kind == 3 ? 0.0f : 1.0f, beta = kind == 0 ? 0.0f : (kind == 1 ? 1.0f : -1.0f);
-        const int ra = kind == 0 ? 0 : 1, rb = kind == 3 ? 3 : 2;
-        const float ca = kind == 2 ? -1.0f : 1.0f, cb = (kind == 1 || kind == 2) ? 1.0f : -1.0f;
+        auto a_row = [](int i, float& al, float& be) { al = i == 3 ? 0.0f : 1.0f; be = i == 0 ? 0.0f : (i == 1 ? 1.0f : -1.0f); };
+        const bool p_role = KPW == 1 || wv < 4, v_role = KPW == 1 ? wv < 4 : wv >= 4;
+        const int vi = KPW == 1 ? grp : 2 * grp + ((wv - 4) >> 1);             // the frequency row of this wave's input items
+        const int ra = vi == 0 ? 0 : 1, rb = vi == 3 ? 3 : 2;
+        const float ca = vi == 2 ? -1.0f : 1.0f, cb = (vi == 1 || vi == 2) ? 1.0f : -1.0f;
         const float inv_tw = 1.0f / (float)TW, inv_th = 1.0f / (float)TH;
         const int pk = tid / PQ, pq = tid % PQ;                  // dY item: tile pk of the stage, channel quad pq
-        const int vk = tid / VQ, vq = tid % VQ;                  // input item (threads 0 .. 255)
+        const int vt = KPW == 1 ? tid : (tid & 127);             // input item index inside its row
+        const int vk = vt / VQ, vq = vt % VQ;
         auto coords = [&](int tile, int& b, int& ty, int& tx) { // tile -> (image, tile row, tile column); tile < 2^24
             int row = (int)((float)tile * inv_tw);
             int r = tile - row * TW;
@@ -89,8 +102,8 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
             b = bb; ty = row - bb * TH; tx = r;
         };
         // Buffer loads: 32-bit byte offsets against one descriptor per tensor, and the hardware range check returns zeros for
-        // an offset past the end -- a pixel outside the image (or a tile past the last one) gets offset 2^31 (the tensors are smaller: checked by the host) instead of a
-        // pointer select against a zero page: 1-2 VALU instructions per load instead of 5-6.
+        // an offset past the end -- a pixel outside the image (or a tile past the last one) gets offset 2^31 (the tensors are smaller:
+        // checked by the host) instead of a pointer select against a zero page: 1-2 VALU instructions per load instead of 5-6.
         const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, B * H * W * COUT * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a), 0, B * H * W * CIN * 4, 0x00020000);
         auto ld = [&](const __amdgpu_buffer_rsrc_t r, unsigned off) {
@@ -128,7 +141,7 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
                 }
             }
         };
-        auto put = [&](unsigned char* img, int plane, const float4& v) {           // img: the item's address in frequency j's first plane
+        auto put = [&](unsigned char* img, int plane, const float4& v) {           // img: the item's address in a frequency's first plane
             uint2 hh, mm, ll;
             split3_quad(v, hh, mm, ll);
             *reinterpret_cast<uint2*>(img) = hh;
@@ -136,18 +149,23 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
             *reinterpret_cast<uint2*>(img + 2 * plane) = ll;
         };
         auto stage_p = [&](unsigned char* buf) {
-            const float4 p0 = wgw_lin(alpha, y[0][0], beta, y[1][0]), p1 = wgw_lin(alpha, y[0][1], beta, y[1][1]);
-            unsigned char* img = buf + wgw_off<ZW>(pk, 8 * pq);
-            put(img, PPLANE, p0);
-            put(img + 3 * PPLANE, PPLANE, wgw_add(p0, p1));
-            put(img + 6 * PPLANE, PPLANE, wgw_sub(p0, p1));
-            put(img + 9 * PPLANE, PPLANE, wgw_neg(p1));
+#pragma unroll
+            for (int il = 0; il < KPW; ++il) {
+                float al, be;
+                a_row(KPW * grp + il, al, be);
+                const float4 p0 = wgw_lin(al, y[0][0], be, y[1][0]), p1 = wgw_lin(al, y[0][1], be, y[1][1]);
+                unsigned char* img = buf + il * 12 * PPLANE + wgw_off<ZW>(pk, 8 * pq);
+                put(img, PPLANE, p0);
+                put(img + 3 * PPLANE, PPLANE, wgw_add(p0, p1));
+                put(img + 6 * PPLANE, PPLANE, wgw_sub(p0, p1));
+                put(img + 9 * PPLANE, PPLANE, wgw_neg(p1));
+            }
         };
         auto stage_v = [&](unsigned char* buf) {
             float4 v[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = wgw_lin(ca, d[0][c], cb, d[1][c]);
-            unsigned char* img = buf + 12 * PPLANE + wgw_off<AW>(vk, 8 * vq);
+            unsigned char* img = buf + NF * 3 * PPLANE + (vi - KPW * grp) * 12 * VPLANE + wgw_off<AW>(vk, 8 * vq);
             put(img, VPLANE, wgw_sub(v[0], v[2]));
             put(img + 3 * VPLANE, VPLANE, wgw_add(v[1], v[2]));
             put(img + 6 * VPLANE, VPLANE, wgw_sub(v[2], v[1]));
@@ -155,26 +173,34 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
         };
         // One register set: a thread re-issues an item's loads for stage s + 1 after it has consumed those of stage s.  (Tried: two
         // sets with the next stage's loads issued in front of the transform, every thread a dY item and HALF an input item as
-        // float2 -- 8-byte loads and 4-byte LDS stores: 13 % slower; the steps are bound by the producers' instruction count, not by
-        // the load latency.)
-        if (wv < 4) {                                            // waves 0-3: a dY item and an input item; their SIMD partners 4-7: a dY item
+        // float2 -- 8-byte loads and 4-byte LDS stores: 13 % slower; the steps are bound by the producers' instruction count and by
+        // the bytes they pull in, not by the load latency.)
+        if (p_role && v_role) {
             fetch_p(s_begin);
             fetch_v(s_begin);
 #pragma unroll 1
             for (int s = 0; s < nst; ++s) {
                 unsigned char* buf = wgl + (s & 1) * STAGE;
                 stage_p(buf);
-                fetch_p(s_begin + s + 1);                        // (past the strip's end: valid addresses, never used)
+                fetch_p(s_begin + s + 1);                        // (past the strip's end: valid or range-checked addresses, never used)
                 stage_v(buf);
                 fetch_v(s_begin + s + 1);
                 tn2_barrier();
             }
-        } else {
+        } else if (p_role) {
             fetch_p(s_begin);
 #pragma unroll 1
             for (int s = 0; s < nst; ++s) {
                 stage_p(wgl + (s & 1) * STAGE);
                 fetch_p(s_begin + s + 1);
+                tn2_barrier();
+            }
+        } else {
+            fetch_v(s_begin);
+#pragma unroll 1
+            for (int s = 0; s < nst; ++s) {
+                stage_v(wgl + (s & 1) * STAGE);
+                fetch_v(s_begin + s + 1);
                 tn2_barrier();
             }
         }
@@ -183,31 +209,31 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
     }
 
     // ================= consumers ==================================================================================================
-    const int cw = wv - 8, j = cw >> 1, mh = cw & 1, i32 = lane & 31, kgrp = lane >> 5;
-    f32x16 acc[MT2][NT];
+    const int cw = wv - 8, f = cw / WPF, mh = cw % WPF, i32 = lane & 31, kgrp = lane >> 5;      // frequency f = (row inside the group) * 4 + j
+    f32x16 acc[MTW][NT];
 #pragma unroll
-    for (int m = 0; m < MT2; ++m)
+    for (int m = 0; m < MTW; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
     const int tq = (lane >> 2) & 3, tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3), tk = 8 * kgrp + tq;
-    int poff[MT2], voff[NT];
+    int poff[MTW], voff[NT];
 #pragma unroll
-    for (int m = 0; m < MT2; ++m) poff[m] = j * 3 * PPLANE + wgw_off<ZW>(tk, 2 * ((mh * MT2 + m) * 32 + tcol));
+    for (int m = 0; m < MTW; ++m) poff[m] = f * 3 * PPLANE + wgw_off<ZW>(tk, 2 * ((mh * MTW + m) * 32 + tcol));
 #pragma unroll
-    for (int n = 0; n < NT; ++n) voff[n] = 12 * PPLANE + j * 3 * VPLANE + wgw_off<AW>(tk, 2 * (n * 32 + tcol));
+    for (int n = 0; n < NT; ++n) voff[n] = NF * 3 * PPLANE + f * 3 * VPLANE + wgw_off<AW>(tk, 2 * (n * 32 + tcol));
     tn2_barrier();                                               // step 0: the producers write stage 0
 #pragma unroll 1
     for (int s = 1; s <= nst; ++s) {
         const unsigned char* sb = wgl + ((s - 1) & 1) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < TPS / 16; ++ks) {
-            bf16x8 af[MT2][3], bf[NT][3];
+            bf16x8 af[MTW][3], bf[NT][3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
 #pragma unroll
-                for (int m = 0; m < MT2; ++m) af[m][p] = tn_tr_fragment<ZW>(sb + poff[m] + p * PPLANE + ks * 16 * ZW);
+                for (int m = 0; m < MTW; ++m) af[m][p] = tn_tr_fragment<ZW>(sb + poff[m] + p * PPLANE + ks * 16 * ZW);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) bf[n][p] = tn_tr_fragment<AW>(sb + voff[n] + p * VPLANE + ks * 16 * AW);
             }
@@ -215,21 +241,21 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
 #pragma unroll
             for (int t6 = 0; t6 < 6; ++t6)
 #pragma unroll
-                for (int m = 0; m < MT2; ++m)
+                for (int m = 0; m < MTW; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][PA[t6]], bf[n][PB[t6]], acc[m][n], 0, 0, 0);
         }
         tn2_barrier();
     }
-    float* out = slab + ((size_t)(strip * 4 + kind) * 4 + j) * COUT * CIN;
+    float* out = slab + ((size_t)strip * 16 + (KPW * grp) * 4 + f) * COUT * CIN;     // [strip][i][j]: i = KPW grp + f / 4, j = f % 4
 #pragma unroll
-    for (int m = 0; m < MT2; ++m)
+    for (int m = 0; m < MTW; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = (mh * MT2 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp, ci = n * 32 + i32;
+                const int co = (mh * MTW + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp, ci = n * 32 + i32;
                 out[(size_t)co * CIN + ci] = acc[m][n][r];
             }
 }

@@ -189,8 +189,9 @@ def test_fallback_conv_kernels_keep_parity(mask):
     the first-generation / direct kernels, which shapes outside the new kernel's range still use.  The switch is read once per
     process, so the reference-golden inference and training-step tests run again in a child with the stages switched off
     (0) or mixed (5: conv3 direct, the others on): both sets of kernels stay correct.  SIR_TN2 does the same for the GRU backward
-    GEMMs (producer / consumer kernel by default; 0 = the first kernel everywhere, 2 = only the 128-row dX on the new one)."""
-    env = dict(os.environ, SIR_WINO2=mask, SIR_TN2={"0": "0", "5": "2"}[mask])
+    GEMMs (producer / consumer kernel by default; 0 = the first kernel everywhere, 2 = only the 128-row dX on the new one) and
+    SIR_WGW for the convolution weight gradients (Winograd form by default; 0 = the nine-tap kernel, 1 = conv2 only)."""
+    env = dict(os.environ, SIR_WINO2=mask, SIR_TN2={"0": "0", "5": "2"}[mask], SIR_WGW={"0": "0", "5": "1"}[mask])
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu",
                         os.path.join(ROOT, "tests", "test_model_gpu.py::test_eval_golden_from_reference"),
                         os.path.join(ROOT, "tests", "test_model_gpu.py::test_stages_vs_oracle"),
