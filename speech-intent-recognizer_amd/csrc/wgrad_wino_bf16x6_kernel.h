@@ -118,8 +118,10 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
             const unsigned rowb = (unsigned)W * COUT * 4u;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                y[r][0] = ld(rz, base + r * rowb);
-                y[r][1] = ld(rz, 2 * tx + 1 < W ? base + r * rowb + COUT * 4u : 0x80000000u);
+                // (a group of ONE row that uses one dY row only -- rows 0 and 3: alpha or beta = 0 -- does not fetch the other)
+                const bool used = KPW == 2 || !((r == 1 && grp == 0) || (r == 0 && grp == 3));
+                y[r][0] = ld(rz, used ? base + r * rowb : 0x80000000u);
+                y[r][1] = ld(rz, used && 2 * tx + 1 < W ? base + r * rowb + COUT * 4u : 0x80000000u);
             }
         };
         auto fetch_v = [&](int stage) {
