@@ -521,7 +521,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         }
         {
             SirProfScope prof(h, SIR_K_B_WGRAD3, st);
-            if (sir_wgw_mask() & 2) {
+            if ((sir_wgw_mask() & 2) && (size_t)B * 16 * d.wp2 * 128 * 4 < ((size_t)1 << 31)) {      // (32-bit buffer offsets)
                 // Winograd form: 16 products per tile and channel pair instead of 36 (wgrad_wino_bf16x6_kernel.h)
                 using Cfg3 = WgwCfg<64, 128>;
                 const int strips = wgrad_wino_strips(B, 16, d.wp2, Cfg3::TPS, Cfg3::groups);
@@ -577,7 +577,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         }
         {
             SirProfScope prof(h, SIR_K_B_WGRAD2, st);
-            if (sir_wgw_mask() & 1) {
+            if ((sir_wgw_mask() & 1) && (size_t)B * 32 * d.wp1 * 64 * 4 < ((size_t)1 << 31)) {
                 using Cfg2 = WgwCfg<32, 64>;
                 const int strips = wgrad_wino_strips(B, 32, d.wp1, Cfg2::TPS, Cfg2::groups);
                 hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<32, 64>), dim3(Cfg2::groups * strips), dim3(WGW_THREADS), Cfg2::lds_bytes, st,
