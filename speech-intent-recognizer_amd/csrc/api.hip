@@ -45,7 +45,7 @@ int sir_wgw_mask() {
 }
 
 int sir_tn2_mask() {
-    static const int m = getenv("SIR_TN2") ? atoi(getenv("SIR_TN2")) : 7;
+    static const int m = getenv("SIR_TN2") ? atoi(getenv("SIR_TN2")) : 15;
     return m;
 }
 

@@ -227,3 +227,22 @@ __global__ __launch_bounds__(TN2_THREADS, TN2_THREADS / 256) void gemm_tn2_bf16x
             }
         }
 }
+
+// out = (half0 + half1) [* dropout mask / (1 - p)]: the two K halves of a split layer-input gradient (float4 per thread; n4 = elements / 4)
+static __global__ __launch_bounds__(256) void dx_halves_add_kernel(const float* __restrict__ halves, size_t n4, float* __restrict__ out, float drop_p,
+                                                                   unsigned long long seed) {
+    const float4* h0 = reinterpret_cast<const float4*>(halves);
+    const float4* h1 = h0 + n4;
+    const float sc = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 a = h0[i], b = h1[i];
+        float4 v = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        if (drop_p > 0.0f) {
+            v.x = tn_dropout_keep(seed, 4 * i, drop_p) ? v.x * sc : 0.0f;
+            v.y = tn_dropout_keep(seed, 4 * i + 1, drop_p) ? v.y * sc : 0.0f;
+            v.z = tn_dropout_keep(seed, 4 * i + 2, drop_p) ? v.z * sc : 0.0f;
+            v.w = tn_dropout_keep(seed, 4 * i + 3, drop_p) ? v.w * sc : 0.0f;
+        }
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}

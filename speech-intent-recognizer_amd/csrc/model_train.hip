@@ -42,6 +42,13 @@ static inline void tn_x6_plan(int tokens, int in_sz, int* tiles, int* kchunk, in
     *slab_floats = (size_t)ns * 2 * 768 * ((size_t)in_sz + 256);
 }
 
+// the layer-input gradient dX = dG [W; W_reverse] of a layer whose 128-row tiles would leave CUs idle (layer 1: 6400 x 512 = 100
+// tiles) runs as TWO K halves on 128-row tiles (wave tile 64 x 64) plus an ordered add, instead of 64-row tiles (wave tile 64 x 32)
+static inline bool dx_splitk(int tokens, int in_sz) {
+    const int nt = ((tokens + TN2_BM - 1) / TN2_BM) * ((in_sz + TN_BN - 1) / TN_BN);
+    return (sir_tn2_mask() & 2) && (sir_tn2_mask() & 8) && nt < 160 && 2 * nt >= 96;
+}
+
 struct TDims {
     int B, T, wp1, wp2, wp3, S;
     int c1gx, c1gy;          // conv1 grids (ceil over un-pooled odd columns)
@@ -116,6 +123,7 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
         size_t need;
         tn_x6_plan(d.B * d.S, in_sz, &t_, &kc_, &ns_, &need);
         if (need > slab) slab = need;
+        if (dx_splitk((int)(d.B * d.S), in_sz) && (size_t)2 * d.B * d.S * in_sz > slab) slab = (size_t)2 * d.B * d.S * in_sz;
     }
     if ((size_t)64 * 16 * 128 * 64 > slab) slab = (size_t)64 * 16 * 128 * 64;      // Winograd weight-gradient slabs: 64 strips of conv3, 128 of conv2
     n[TB_SLAB] = slab + (size_t)WGR_PARTS * 16 * 128 * 64;      // + the partial sums of the two-pass wgrad reduce
@@ -476,7 +484,15 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             jn.tile0[0] = 0;
             const int ntn = (in_sz + TN_BN - 1) / TN_BN;
             int ntiles = ((M + TN_BM - 1) / TN_BM) * ntn;
-            if (ntiles < 160) {                              // too few 128-row tiles to fill the CUs: 64-row tiles
+            if (dx_splitk(M, in_sz)) {
+                jn.drop_p = 0.0f;                                // (the dropout mask is applied by the add)
+                jn.slab[0] = p.slab; jn.slab_stride[0] = (size_t)M * in_sz;
+                jn.tile0[1] = ntiles;
+                hipLaunchKernelGGL(gemm_tn2_bf16x6_kernel<false>, dim3(ntiles, 2), dim3(TN2_THREADS), tn2_lds_bytes(false), st, jn, M, 1536, 768, 1);
+                const bool drop = layer == 1 && dropout_p > 0.0f;
+                hipLaunchKernelGGL(dx_halves_add_kernel, dim3(grid_for((size_t)M * in_sz / 4)), dim3(256), 0, st, (const float*)p.slab, (size_t)M * in_sz / 4,
+                                   dxin, drop ? dropout_p : 0.0f, (unsigned long long)dropout_seed);
+            } else if (ntiles < 160) {                       // too few 128-row tiles to fill the CUs: 64-row tiles
                 ntiles = ((M + 63) / 64) * ntn;
                 jn.tile0[1] = ntiles;
                 if (sir_tn2_mask() & 4)

@@ -161,7 +161,7 @@ static inline int sir_cluster_leave(sir_handle* h, hipStream_t st) {
 // devtools/gpu_ab_wino2.sh, profiles/r03/ab_wino2.txt)
 int sir_wino2_mask();
 int sir_wgw_mask();      // SIR_WGW: convolution weight gradients in Winograd form: bit 0 = conv2, bit 1 = conv3 (default 3)
-int sir_tn2_mask();      // SIR_TN2: GRU backward GEMMs on the producer / consumer kernel: bit 0 = dW, bit 1 = dX on 128-row tiles, bit 2 = dX on 64-row tiles (default 7)
+int sir_tn2_mask();      // SIR_TN2: GRU backward GEMMs on the producer / consumer kernel: bit 0 = dW, bit 1 = dX on 128-row tiles, bit 2 = dX on 64-row tiles, bit 3 = a dX that would take 64-row tiles runs as two K halves on 128-row tiles instead (default 15)
 void sir_set_error(const char* fmt, ...);
 int sir_check_hip(hipError_t e, const char* what);
 
