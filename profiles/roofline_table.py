@@ -57,7 +57,8 @@ ROWS = [
     ("gemm_tn2_bf16x6_kernel<true", "GRU dW = dG^T X (l1, l0: mean)", "train", "mfma6", (F["bwd_gru_dw_l0"] + F["bwd_gru_dw_l1"]) * B // 2,
      (2 * B * S * 1536 * 4 + B * S * (1024 + 512) * 4 // 2 + B * S * 512 * 4)),
     ("gemm_tn2_bf16x6_kernel<false, 0, 64", "GRU dX l1", "train", "mfma6", F["bwd_gru_dx_l1"] * B, GI + Y),
-    ("gemm_tn2_bf16x6_kernel<false, 0, 128", "GRU dX l0", "train", "mfma6", F["bwd_gru_dx_l0"] * B, GI + X0),
+    ("gemm_tn2_bf16x6_kernel<false, 0, 128", "GRU dX (l0; l1 as two K halves: mean of the two launches)", "train", "mfma6",
+     (F["bwd_gru_dx_l0"] + F["bwd_gru_dx_l1"]) * B // 2, GI + (X0 + Y) // 2),
     ("gemm_tn_bf16x6_kernel<true", "GRU dW = dG^T X (l1, l0: mean)", "train", "mfma6", (F["bwd_gru_dw_l0"] + F["bwd_gru_dw_l1"]) * B // 2,
      (2 * B * S * 1536 * 4 + B * S * (1024 + 512) * 4 // 2 + B * S * 512 * 4)),
     ("gemm_tn_bf16x6_kernel<false, 64", "GRU dX l1", "train", "mfma6", F["bwd_gru_dx_l1"] * B, GI + Y),
