@@ -751,11 +751,22 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const float* __restrict_
     const int c4n = C / 4, Hc = (H + 1) / 2, Wc = (W + 1) / 2;           // cells cover an odd last row / column too
     const size_t total = (size_t)B * Hc * Wc * c4n;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int cc = idx % c4n;
-        size_t rest = idx / c4n;
-        const int cx = rest % Wc; rest /= Wc;
-        const int cy = rest % Hc;
-        const int b = rest / Hc;
+        int cc, cx, cy, b;
+        if (GRU_IN) {
+            // the pooled gradient is [b][px][c][py] here: with the cell ROW as the fastest thread index eight lanes read one 32-byte
+            // row of it (channel-fastest threads picked one float out of every row: 373 MB of traffic for 236 MB of work)
+            cy = idx % Hc;
+            size_t rest = idx / Hc;
+            cc = rest % c4n; rest /= c4n;
+            cx = rest % Wc;
+            b = rest / Wc;
+        } else {
+            cc = idx % c4n;
+            size_t rest = idx / c4n;
+            cx = rest % Wc; rest /= Wc;
+            cy = rest % Hc;
+            b = rest / Hc;
+        }
         const float4 s = *reinterpret_cast<const float4*>(scale + cc * 4), t = *reinterpret_cast<const float4*>(shift + cc * 4);
         const float4 mu = *reinterpret_cast<const float4*>(mean + cc * 4), is = *reinterpret_cast<const float4*>(invstd + cc * 4);
         const float4 m1 = *reinterpret_cast<const float4*>(mdy + cc * 4), m2 = *reinterpret_cast<const float4*>(mdyx + cc * 4);
