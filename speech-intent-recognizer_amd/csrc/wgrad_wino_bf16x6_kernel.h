@@ -109,8 +109,7 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
         auto ld = [&](const __amdgpu_buffer_rsrc_t r, unsigned off) {
             return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
         };
-        float4 y[2][2], d[2][4];
-        auto fetch_p = [&](int stage) {
+        auto fetch_p = [&](int stage, float4 (&y)[2][2]) {
             const int tile = stage * TPS + pk;
             int b, ty, tx;
             coords(tile, b, ty, tx);
@@ -124,7 +123,7 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
                 y[r][1] = ld(rz, used && 2 * tx + 1 < W ? base + r * rowb + COUT * 4u : 0x80000000u);
             }
         };
-        auto fetch_v = [&](int stage) {
+        auto fetch_v = [&](int stage, float4 (&d)[2][4]) {
             const int tile = stage * TPS + vk;
             int b, ty, tx;
             coords(tile, b, ty, tx);
@@ -150,7 +149,7 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
             *reinterpret_cast<uint2*>(img + plane) = mm;
             *reinterpret_cast<uint2*>(img + 2 * plane) = ll;
         };
-        auto stage_p = [&](unsigned char* buf) {
+        auto stage_p = [&](unsigned char* buf, const float4 (&y)[2][2]) {
 #pragma unroll
             for (int il = 0; il < KPW; ++il) {
                 float al, be;
@@ -163,7 +162,7 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
                 put(img + 9 * PPLANE, PPLANE, wgw_neg(p1));
             }
         };
-        auto stage_v = [&](unsigned char* buf) {
+        auto stage_v = [&](unsigned char* buf, const float4 (&d)[2][4]) {
             float4 v[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = wgw_lin(ca, d[0][c], cb, d[1][c]);
@@ -173,40 +172,52 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
             put(img + 6 * VPLANE, VPLANE, wgw_sub(v[2], v[1]));
             put(img + 9 * VPLANE, VPLANE, wgw_sub(v[1], v[3]));
         };
-        // One register set: a thread re-issues an item's loads for stage s + 1 after it has consumed those of stage s.  (Tried: two
-        // sets with the next stage's loads issued in front of the transform, every thread a dY item and HALF an input item as
-        // float2 -- 8-byte loads and 4-byte LDS stores: 13 % slower; the steps are bound by the producers' instruction count and by
-        // the bytes they pull in, not by the load latency.)
+        // Loads run TWO stages ahead where the registers allow it (two sets: an item's loads for stage s + 2 are issued right after
+        // stage s has consumed the set): with one set the loads of stage s + 1 are issued at the END of step s and only the barrier
+        // wait covers them -- one stage of bytes in flight per CU is what the 32 -> 64 kernel's 33 GB/s per CU came from.  Steps in
+        // pairs; the consumers add the odd barrier.  (64 -> 128: waves 0-3 carry a dY item AND an input item, 48 registers per set;
+        // two sets there cost the consumers' accumulators their room, so those waves keep one.)
+        const int npair = nst / 2 + 1;
         if (p_role && v_role) {
-            fetch_p(s_begin);
-            fetch_v(s_begin);
+            float4 y[2][2], d[2][4];
+            fetch_p(s_begin, y);
+            fetch_v(s_begin, d);
 #pragma unroll 1
-            for (int s = 0; s < nst; ++s) {
+            for (int s = 0; s < 2 * npair; ++s) {
                 unsigned char* buf = wgl + (s & 1) * STAGE;
-                stage_p(buf);
-                fetch_p(s_begin + s + 1);                        // (past the strip's end: valid or range-checked addresses, never used)
-                stage_v(buf);
-                fetch_v(s_begin + s + 1);
+                stage_p(buf, y);
+                fetch_p(s_begin + s + 1, y);                     // (past the strip's end: valid or range-checked addresses, never used)
+                stage_v(buf, d);
+                fetch_v(s_begin + s + 1, d);
                 tn2_barrier();
             }
         } else if (p_role) {
-            fetch_p(s_begin);
+            float4 y0[2][2], y1[2][2];
+            fetch_p(s_begin, y0);
+            fetch_p(s_begin + 1, y1);
 #pragma unroll 1
-            for (int s = 0; s < nst; ++s) {
-                stage_p(wgl + (s & 1) * STAGE);
-                fetch_p(s_begin + s + 1);
+            for (int s = 0; s < 2 * npair; s += 2) {
+                stage_p(wgl, y0);
+                fetch_p(s_begin + s + 2, y0);
+                tn2_barrier();
+                stage_p(wgl + STAGE, y1);
+                fetch_p(s_begin + s + 3, y1);
                 tn2_barrier();
             }
         } else {
-            fetch_v(s_begin);
+            float4 d0[2][4], d1[2][4];
+            fetch_v(s_begin, d0);
+            fetch_v(s_begin + 1, d1);
 #pragma unroll 1
-            for (int s = 0; s < nst; ++s) {
-                stage_v(wgl + (s & 1) * STAGE);
-                fetch_v(s_begin + s + 1);
+            for (int s = 0; s < 2 * npair; s += 2) {
+                stage_v(wgl, d0);
+                fetch_v(s_begin + s + 2, d0);
+                tn2_barrier();
+                stage_v(wgl + STAGE, d1);
+                fetch_v(s_begin + s + 3, d1);
                 tn2_barrier();
             }
         }
-        tn2_barrier();
         return;
     }
 
@@ -250,6 +261,7 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
         }
         tn2_barrier();
     }
+    if (!(nst & 1)) tn2_barrier();                               // the odd step of the producers' last pair
     float* out = slab + ((size_t)strip * 16 + (KPW * grp) * 4 + f) * COUT * CIN;     // [strip][i][j]: i = KPW grp + f / 4, j = f % 4
 #pragma unroll
     for (int m = 0; m < MTW; ++m)
