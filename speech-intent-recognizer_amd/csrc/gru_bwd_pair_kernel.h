@@ -31,7 +31,11 @@ __global__ __launch_bounds__(GP_THREADS) void gru_bwd_pair_kernel(
     gp_f4* wl4 = reinterpret_cast<gp_f4*>(blds);                          // [GBP_LDS4][threads] float4 (4 consecutive own rows)
     float* gsh = blds + (size_t)GBP_LDS4 * GP_THREADS * 4;                // dgh of the own rows: [utterance][384]
     float* dhs = gsh + GP_BW * 384;                                       // (W_hh^T dgh) of the own units: [utterance][128]
-    const int dir = blockIdx.y, pair = blockIdx.x >> 1, half = blockIdx.x & 1;
+    // the two halves of a pair on ONE XCD (workgroup L = x + gridDim.x y runs on XCD L % 8; gridDim.x = 2 pairs): x, x + 8 of a block of 16
+    const int npairs_ = gridDim.x >> 1;
+    const int dir = blockIdx.y;
+    const int half = (npairs_ & 7) == 0 ? (blockIdx.x >> 3) & 1 : blockIdx.x & 1;
+    const int pair = (npairs_ & 7) == 0 ? (blockIdx.x & 7) + 8 * (blockIdx.x >> 4) : blockIdx.x >> 1;
     const int b0 = pair * GP_BW;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* __restrict__ whh = dir ? whh1 : whh0;

@@ -18,7 +18,7 @@ int sir_launch_gru_quad(sir_handle* h, hipStream_t st, bool save, const float* g
         sir_set_error("gru_quad: exchange buffer allocation failed");
         return SIR_EHIP;
     }
-    const dim3 grid(4, (unsigned)clusters);
+    const dim3 grid(4 * (unsigned)clusters);
     // SIR_GRU_DBG: timing knock-outs and fault injection of gru_quad_kernel (see its `dbg` comment); 0 in production
     static const int dbg = getenv("SIR_GRU_DBG") ? atoi(getenv("SIR_GRU_DBG")) : 0;
     if (save)

@@ -80,7 +80,14 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     // peers time out), bit 4 = spin limit 4096 instead of 2^22 (so that the injected timeout takes milliseconds);
     // bits 8-12 = extra delay of the first poll round in units of 64 cycles (results stay valid)
     extern __shared__ __attribute__((aligned(16))) unsigned char qlds[];
-    const int q = blockIdx.x, cluster = blockIdx.y;
+    // blockIdx.x = L -> (quarter, cluster).  Workgroup L runs on XCD L % 8 (round-robin dispatch): with the clusters in eights the four
+    // quarters of a cluster are L = x, x + 8, x + 16, x + 24 of a block of 32 -- one XCD, so that the per-step exchange stays inside
+    // that XCD's L2 instead of crossing the fabric (correctness does not depend on the placement: the granule stores / loads are
+    // agent-scope either way)
+    const int nclusters = gridDim.x >> 2;
+    const bool xcd_order = (nclusters & 7) == 0 && !(dbg & 32);          // (dbg bit 5: plain order, for the A/B)
+    const int q = xcd_order ? (blockIdx.x >> 3) & 3 : blockIdx.x & 3;
+    const int cluster = xcd_order ? (blockIdx.x & 7) + 8 * (blockIdx.x >> 5) : blockIdx.x >> 2;
     const int dir = cluster & 1, grp = cluster >> 1;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 15, kg = lane >> 4;                 // MFMA column (utterance) / k-group and D row group
