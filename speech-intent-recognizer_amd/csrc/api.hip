@@ -49,6 +49,11 @@ int sir_tn2_mask() {
     return m;
 }
 
+int sir_bwd_streams() {
+    static const int m = getenv("SIR_BWD_STREAMS") ? atoi(getenv("SIR_BWD_STREAMS")) : 0;
+    return m;
+}
+
 extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     if (!cfg || !out) { sir_set_error("sir_create: NULL argument"); return SIR_EINVAL; }
     if (cfg->n_fft != SIR_NFFT || cfg->hop_length != SIR_HOP) {
@@ -74,6 +79,8 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     h->zero_page = nullptr; h->num_cus = 256;
     for (auto& x : h->xbufs) { x.st = nullptr; x.p = nullptr; x.kind = 0; x.cap = 0; x.bytes = 0; x.epoch = 0; x.used = 0; }
     h->xbuf_clock = 0;
+    h->bwd_side = nullptr;
+    for (auto& e : h->bwd_ev) e = nullptr;
     h->cfg = *cfg;
     h->cfg.window = nullptr;
     h->cfg.mel_fb = nullptr;
@@ -160,6 +167,8 @@ extern "C" int sir_destroy(sir_handle* h) {
     (void)hipFree(h->tw512); (void)hipFree(h->tw1024); (void)hipFree(h->window);
     (void)hipFree(h->melw); (void)hipFree(h->mel_desc); (void)hipFree(h->status);
     if (h->cluster_done) (void)hipEventDestroy(h->cluster_done);
+    if (h->bwd_side) { (void)hipStreamSynchronize(h->bwd_side); (void)hipStreamDestroy(h->bwd_side); }
+    for (auto e : h->bwd_ev) if (e) (void)hipEventDestroy(e);
     for (auto& x : h->xbufs) (void)hipFree(x.p);
     (void)hipFree(h->zero_page);
     for (auto& t : h->resample_tables) { (void)hipFree(t.taps); (void)hipFree(t.first); }

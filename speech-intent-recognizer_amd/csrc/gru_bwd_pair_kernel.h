@@ -21,8 +21,20 @@
 constexpr int GBP_G4 = 24;                     // groups of 4 own rows per row part (96 rows), for each of the thread's two k
 constexpr int GBP_REG1 = 6;                    // groups of the second k kept in registers (the first k: all 24) -> 120 VGPRs
 constexpr int GBP_LDS4 = GBP_G4 - GBP_REG1;    // groups of the second k kept in LDS (18 x 8 KB)
-constexpr size_t GBP_LDS_BYTES = ((size_t)GBP_LDS4 * GP_THREADS * 4 + GP_BW * 384 + GP_BW * GP_UH) * 4;
+// dgh of the own rows in LDS: [utterance][row part][GBP_RPS].  A ds_read_b128 of the product loop serves 16 lanes = 4 row parts x 4
+// lanes reading the same 16 bytes; with the parts 96 floats = 384 B apart (round 3) parts 0 / 2 and 1 / 3 sat on the same banks
+// (384 = 128 mod 256): a 2-way conflict on all 96 reads per thread and step (PMC r03: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE =
+// 0.45, the LDS pipe busy 57 % of the kernel).  100 floats = 400 B puts the four parts at byte 0 / 144 / 32 / 176 of the 256-byte
+// bank line: four disjoint 16-byte slots.
+constexpr int GBP_RPS = 100;
+constexpr int gbp_gs(bool pad) { return pad ? 4 * GBP_RPS : 384; }      // floats per utterance
+constexpr size_t GBP_LDS_BYTES = ((size_t)GBP_LDS4 * GP_THREADS * 4 + GP_BW * gbp_gs(true) + GP_BW * GP_UH) * 4;
 
+// KNOCK (timing knock-outs, SIR_BPTT_KNOCK; results invalid unless 0): bit 0 = no exchange with the peer (no granule store, no
+// poll), bit 1 = no product loop, bit 2 = product loop without its dgh reads from LDS, bit 3 = product loop without the LDS-resident
+// weights (the register-resident ones stand in).  PAD = the padded dgh image above (false: round 3's), PK = the product loop on
+// v_pk_fma_f32 (even / odd partial sums per accumulator, added once per step).
+template <int KNOCK = 0, bool PAD = true, bool PK = false>
 __global__ __launch_bounds__(GP_THREADS) void gru_bwd_pair_kernel(
     const float* __restrict__ dy, const float* __restrict__ gates, const float* __restrict__ y, const float* __restrict__ whh0,
     const float* __restrict__ whh1, float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ bsum_i,
@@ -30,7 +42,8 @@ __global__ __launch_bounds__(GP_THREADS) void gru_bwd_pair_kernel(
     extern __shared__ __attribute__((aligned(16))) float blds[];
     gp_f4* wl4 = reinterpret_cast<gp_f4*>(blds);                          // [GBP_LDS4][threads] float4 (4 consecutive own rows)
     float* gsh = blds + (size_t)GBP_LDS4 * GP_THREADS * 4;                // dgh of the own rows: [utterance][384]
-    float* dhs = gsh + GP_BW * 384;                                       // (W_hh^T dgh) of the own units: [utterance][128]
+    constexpr int GS = gbp_gs(PAD), RPS = PAD ? GBP_RPS : 96;
+    float* dhs = gsh + GP_BW * gbp_gs(true);                              // (W_hh^T dgh) of the own units: [utterance][128]
     // the two halves of a pair on ONE XCD (workgroup L = x + gridDim.x y runs on XCD L % 8; gridDim.x = 2 pairs): x, x + 8 of a block of 16
     const int npairs_ = gridDim.x >> 1;
     const int dir = blockIdx.y;
@@ -62,6 +75,10 @@ __global__ __launch_bounds__(GP_THREADS) void gru_bwd_pair_kernel(
     // ---- gate role: unit ul = tid & 127 of this half, utterance bq = tid >> 7 ----------------------------
     const int ul = tid & 127, bq = tid >> 7, u = half * GP_UH + ul;
     const bool bvalid = (b0 + bq) < B;
+    // LDS slot of own row ro = 128 g + ul (gate g): row part ro / 96, position ro % 96 inside it
+    int gslot[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { const int ro = 128 * g + ul; gslot[g] = bq * GS + (ro / 96) * RPS + ro % 96; }
     for (int i = tid; i < GP_BW * GP_UH; i += GP_THREADS) dhs[i] = 0.0f;
     float dhz = 0.0f;
     float sum_r = 0.f, sum_z = 0.f, sum_n = 0.f, sum_nr = 0.f;
@@ -104,29 +121,63 @@ __global__ __launch_bounds__(GP_THREADS) void gru_bwd_pair_kernel(
             sum_r += drp; sum_z += dzp; sum_n += dnp; sum_nr += dnr;
         }
         dhz = dhz_new;
-        gsh[bq * 384 + ul] = drp; gsh[bq * 384 + 128 + ul] = dzp; gsh[bq * 384 + 256 + ul] = dnr;
+        gsh[gslot[0]] = drp; gsh[gslot[1]] = dzp; gsh[gslot[2]] = dnr;
         __syncthreads();                                          // gsh complete; everyone has consumed dhs
 
         // ---- partial of W_hh^T dgh over the own rows ----------------------------------------------------
         float acc0[GP_BW], acc1[GP_BW];
+        const float* gpart = gsh + rp * RPS;
+        if constexpr (!PK) {
 #pragma unroll
-        for (int bb = 0; bb < GP_BW; ++bb) { acc0[bb] = 0.0f; acc1[bb] = 0.0f; }
-        const float* gpart = gsh + rp * 96;
-        auto fma8 = [&](const gp_f4& a, const gp_f4& c, int i) {
+            for (int bb = 0; bb < GP_BW; ++bb) { acc0[bb] = 0.0f; acc1[bb] = 0.0f; }
+            auto fma8 = [&](const gp_f4& a, const gp_f4& c, int i) {
 #pragma unroll
-            for (int bb = 0; bb < GP_BW; ++bb) {
-                const gp_f4 g4 = *reinterpret_cast<const gp_f4*>(gpart + bb * 384 + 4 * i);
-                acc0[bb] = fmaf(a.x, g4.x, acc0[bb]); acc0[bb] = fmaf(a.y, g4.y, acc0[bb]);
-                acc0[bb] = fmaf(a.z, g4.z, acc0[bb]); acc0[bb] = fmaf(a.w, g4.w, acc0[bb]);
-                acc1[bb] = fmaf(c.x, g4.x, acc1[bb]); acc1[bb] = fmaf(c.y, g4.y, acc1[bb]);
-                acc1[bb] = fmaf(c.z, g4.z, acc1[bb]); acc1[bb] = fmaf(c.w, g4.w, acc1[bb]);
+                for (int bb = 0; bb < GP_BW; ++bb) {
+                    gp_f4 g4;
+                    if (KNOCK & 4) g4 = a;
+                    else g4 = *reinterpret_cast<const gp_f4*>(gpart + bb * GS + 4 * i);
+                    acc0[bb] = fmaf(a.x, g4.x, acc0[bb]); acc0[bb] = fmaf(a.y, g4.y, acc0[bb]);
+                    acc0[bb] = fmaf(a.z, g4.z, acc0[bb]); acc0[bb] = fmaf(a.w, g4.w, acc0[bb]);
+                    acc1[bb] = fmaf(c.x, g4.x, acc1[bb]); acc1[bb] = fmaf(c.y, g4.y, acc1[bb]);
+                    acc1[bb] = fmaf(c.z, g4.z, acc1[bb]); acc1[bb] = fmaf(c.w, g4.w, acc1[bb]);
+                }
+            };
+            if (!(KNOCK & 2)) {
+#pragma unroll
+                for (int i = 0; i < GBP_REG1; ++i) fma8(wr0[i], wr1[i], i);
+                asm volatile("" ::: "memory");                        // keep the LDS-resident weights in LDS
+#pragma unroll
+                for (int i = GBP_REG1; i < GBP_G4; ++i)
+                    fma8(wr0[i], (KNOCK & 8) ? wr0[GBP_G4 - 1 - i] : wl4[(size_t)(i - GBP_REG1) * GP_THREADS + tid], i);
             }
-        };
+        } else {
+            // packed form: (even, odd) partial sums per accumulator -- two v_pk_fma_f32 per four products
+            gp_f2 p0[GP_BW], p1[GP_BW];
 #pragma unroll
-        for (int i = 0; i < GBP_REG1; ++i) fma8(wr0[i], wr1[i], i);
-        asm volatile("" ::: "memory");                            // keep the LDS-resident weights in LDS
+            for (int bb = 0; bb < GP_BW; ++bb) { p0[bb] = gp_f2{0.0f, 0.0f}; p1[bb] = gp_f2{0.0f, 0.0f}; }
+            auto fma8 = [&](const gp_f4& a, const gp_f4& c, int i) {
 #pragma unroll
-        for (int i = GBP_REG1; i < GBP_G4; ++i) fma8(wr0[i], wl4[(size_t)(i - GBP_REG1) * GP_THREADS + tid], i);
+                for (int bb = 0; bb < GP_BW; ++bb) {
+                    gp_f4 g4;
+                    if (KNOCK & 4) g4 = a;
+                    else g4 = *reinterpret_cast<const gp_f4*>(gpart + bb * GS + 4 * i);
+                    p0[bb] = __builtin_elementwise_fma(a.xy, g4.xy, p0[bb]);
+                    p0[bb] = __builtin_elementwise_fma(a.zw, g4.zw, p0[bb]);
+                    p1[bb] = __builtin_elementwise_fma(c.xy, g4.xy, p1[bb]);
+                    p1[bb] = __builtin_elementwise_fma(c.zw, g4.zw, p1[bb]);
+                }
+            };
+            if (!(KNOCK & 2)) {
+#pragma unroll
+                for (int i = 0; i < GBP_REG1; ++i) fma8(wr0[i], wr1[i], i);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = GBP_REG1; i < GBP_G4; ++i)
+                    fma8(wr0[i], (KNOCK & 8) ? wr0[GBP_G4 - 1 - i] : wl4[(size_t)(i - GBP_REG1) * GP_THREADS + tid], i);
+            }
+#pragma unroll
+            for (int bb = 0; bb < GP_BW; ++bb) { acc0[bb] = p0[bb].x + p0[bb].y; acc1[bb] = p1[bb].x + p1[bb].y; }
+        }
 #pragma unroll
         for (int bb = 0; bb < GP_BW; ++bb) {                      // the four row parts: lanes 4j .. 4j + 3
             acc0[bb] += gp_quad_xor1(acc0[bb]); acc0[bb] += gp_quad_xor2(acc0[bb]);
@@ -139,15 +190,16 @@ __global__ __launch_bounds__(GP_THREADS) void gru_bwd_pair_kernel(
         const float vown = half ? s1 : s0, vpeer = half ? s0 : s1;
         const unsigned tagv = (epoch << 16) | (unsigned)(it + 1);     // {launch epoch of this buffer, step + 1}: stale granules never match
         if (it + 1 < S) {
-            unsigned long long* gslot = xg + ((size_t)(it & 1) * 2 + half) * GP_BW * GP_UH;
+            unsigned long long* gmine = xg + ((size_t)(it & 1) * 2 + half) * GP_BW * GP_UH;
             const unsigned long long* gpeer = xg + ((size_t)(it & 1) * 2 + (half ^ 1)) * GP_BW * GP_UH;
-            __hip_atomic_store(gslot + rp * GP_UH + kp, ((unsigned long long)tagv << 32) | __float_as_uint(vpeer), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            unsigned long long pv;
-            unsigned spins = 0;
-            while ((unsigned)((pv = __hip_atomic_load(gpeer + rp * GP_UH + kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tagv) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > GP_SPIN_LIMIT) { __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            unsigned long long pv = ((unsigned long long)tagv << 32) | __float_as_uint(vpeer);
+            if (!(KNOCK & 1)) {
+                __hip_atomic_store(gmine + rp * GP_UH + kp, pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while ((unsigned)((pv = __hip_atomic_load(gpeer + rp * GP_UH + kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tagv) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > GP_SPIN_LIMIT) { __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
             }
             dhs[rp * GP_UH + kp] = vown + __uint_as_float((unsigned)pv);     // (dhs was last read before the barrier above)
         }

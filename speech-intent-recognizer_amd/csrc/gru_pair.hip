@@ -1,12 +1,30 @@
 // Launcher of the paired-workgroup GRU backward recurrence (gru_bwd_pair_kernel.h).  Own translation unit because it is
 // compiled with -fno-slp-vectorize: hipcc's SLP pass packs the scalar fmaf chains into v_pk_fma_f32, whose register-pair
 // constraints cost ~180 spilled VGPRs in this register-resident kernel.
+#include <cstdlib>
 #include "gru_bwd_pair_kernel.h"
 
 int sir_launch_gru_bwd_pair(sir_handle* h, hipStream_t st, const float* dy, const float* gates, const float* y, const float* whh0,
                             const float* whh1, float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S) {
+    // SIR_BPTT (A/B and timing knock-outs, devtools/gpu_ab_bptt.sh; default 0 = the product kernel): 1 = round 3's unpadded dgh image,
+    // 2 = product loop on v_pk_fma_f32, 3 = both; 16 + k = knock-out k of the product kernel (see the kernel's KNOCK comment)
+    static const int mode = getenv("SIR_BPTT") ? atoi(getenv("SIR_BPTT")) : 0;
+    typedef void (*kern_t)(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, int, int, float*,
+                           unsigned int*, unsigned);
+    kern_t kern = gru_bwd_pair_kernel<0, true, false>;
+    switch (mode) {
+        case 1: kern = gru_bwd_pair_kernel<0, false, false>; break;
+        case 2: kern = gru_bwd_pair_kernel<0, true, true>; break;
+        case 3: kern = gru_bwd_pair_kernel<0, false, true>; break;
+        case 17: kern = gru_bwd_pair_kernel<1, true, false>; break;
+        case 18: kern = gru_bwd_pair_kernel<2, true, false>; break;
+        case 20: kern = gru_bwd_pair_kernel<4, true, false>; break;
+        case 24: kern = gru_bwd_pair_kernel<8, true, false>; break;
+        case 19: kern = gru_bwd_pair_kernel<3, true, false>; break;
+        default: break;
+    }
     if (!h->attr_gru_bwd) {
-        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_bwd_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GBP_LDS_BYTES));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GBP_LDS_BYTES));
         h->attr_gru_bwd = true;
     }
     const size_t npairs = (B + GP_BW - 1) / GP_BW;
@@ -16,7 +34,7 @@ int sir_launch_gru_bwd_pair(sir_handle* h, hipStream_t st, const float* dy, cons
         sir_set_error("gru_bwd_pair: exchange buffer allocation failed");
         return SIR_EHIP;
     }
-    hipLaunchKernelGGL(gru_bwd_pair_kernel, dim3((unsigned)(npairs * 2), 2), dim3(GP_THREADS), GBP_LDS_BYTES, st, dy, gates, y, whh0, whh1, dgi,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(npairs * 2), 2), dim3(GP_THREADS), GBP_LDS_BYTES, st, dy, gates, y, whh0, whh1, dgi,
                        dgh, bsum_i, bsum_h, B, S, (float*)xbuf, h->status, epoch);
     SIR_HIP_TRY(hipGetLastError());
     return SIR_OK;

@@ -27,6 +27,7 @@ enum TrainBuf {
     TB_GXB,       // (unused: exchange granules live in handle-owned buffers, sir_xbuf_acquire)
     TB_GFL,       // paired GRU status word
     TB_C1M,       // conv1 input moments: 54 doubles (conv1_moments_kernel), forward -> backward
+    TB_DGI1, TB_DGH1,   // gate gradients of GRU layer 1 (TB_DGI / TB_DGH hold layer 0's): layer 1's weight-gradient GEMM may run after layer 0's BPTT
     TB_COUNT
 };
 
@@ -134,6 +135,8 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     n[TB_GXB] = 64;
     n[TB_GFL] = 64;
     n[TB_C1M] = 2 * C1_NMOM;
+    n[TB_DGI1] = B * S * 1536;
+    n[TB_DGH1] = B * S * 1536;
 }
 
 size_t tws_layout(const TDims& d, size_t* off) {
@@ -151,6 +154,7 @@ size_t tws_layout(const TDims& d, size_t* off) {
 
 struct TPtrs {
     float *a1, *z2, *a2, *z3, *x0, *gi, *g0, *g1, *y0, *y0d, *y1, *ctx, *bn, *bnb, *wp2, *wp3, *wht, *wr4, *wp2t, *wp3t;
+    float *dgi1, *dgh1;
     float *dy1, *dy0, *dgi, *dgh, *dx0, *dz3, *da2, *dz2, *da1, *small, *slab;
     float2* stats;
     unsigned short *xs, *wsl0, *wsl1, *wcb2, *wcb3, *wcb2t, *wcb3t, *wcb3d;
@@ -179,6 +183,7 @@ TPtrs carve(void* ws, const size_t* off) {
     p.wcb3d = p.wcb3t + (size_t)3 * 128 * 16 * 64;           // conv3 forward with 9 taps: only for shapes the Winograd kernel does not cover
     p.gfl = (unsigned int*)(b + off[TB_GFL]);
     p.c1m = (double*)(b + off[TB_C1M]);
+    p.dgi1 = (float*)(b + off[TB_DGI1]); p.dgh1 = (float*)(b + off[TB_DGH1]);
     return p;
 }
 
@@ -393,6 +398,79 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
     float* bsum_h = p.slab + (size_t)B * 1536;
     const float* y0in = dropout_p > 0.0f ? p.y0d : p.y0;
 
+    // ---- two-stream form (SIR_BWD_STREAMS=1; A/B in profiles/r04/ab_bwd_streams.txt) ----------------------------------------
+    // The four big launches that nothing downstream waits for -- the GRU weight gradients of both layers and the two convolution
+    // weight gradients, with their slab reduces -- go to a stream owned by the handle: forked once behind the last dX (`ev_gru`),
+    // each convolution weight gradient behind the BatchNorm backward that produces its dz (`ev_dz3`, `ev_dz2`), joined once before
+    // the call returns (`ev_join`).  The chain BN3 -> dgrad3 -> BN2 -> dgrad2 -> conv1 stays on the caller's stream.  In the split
+    // form (SIR_BWD_HEAD_GRU / SIR_BWD_CNN, data parallel) the first half stays on one stream -- its gradients must be final when
+    // it returns -- and the second forks the convolution weight gradients only.
+    if (sir_bwd_streams() && !h->bwd_side) {                 // (first use: the only allocating step, as for the exchange buffers)
+        SIR_HIP_TRY(hipStreamCreateWithFlags(&h->bwd_side, hipStreamNonBlocking));
+        for (auto& e : h->bwd_ev) SIR_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (!h->attr_tn) {
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<true, TN_BM_DW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn_lds_bytes(true, TN_BM_DW)));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES_64));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn2_bf16x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn2_lds_bytes(true)));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn2_bf16x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn2_lds_bytes(false)));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn2_bf16x6_kernel<false, 0, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn2_lds_bytes(false, 64)));
+        h->attr_tn = true;
+    }
+    const bool two = sir_bwd_streams() && h->bwd_side != nullptr;
+    hipStream_t side = two ? h->bwd_side : st;
+    const bool defer_dw = two && part == SIR_BWD_ALL;
+
+    // all four weight-gradient GEMMs of a GRU layer (2 directions x {W_ih, W_hh}) in one bf16x6 launch + the slab reduce
+    auto launch_dw = [&](int layer, hipStream_t s_) -> int {
+        const float* dgi_l = layer ? p.dgi1 : p.dgi;
+        const float* dgh_l = layer ? p.dgh1 : p.dgh;
+        const float* yout = layer ? p.y1 : p.y0;
+        const float* xin = layer ? y0in : p.x0;
+        const int in_sz = layer ? 512 : 1024;
+        SirProfScope prof(h, layer ? SIR_K_B_DW1 : SIR_K_B_DW0, s_);
+        const bool tn2_dw = sir_tn2_mask() & 1;
+        TnJobs jb{};
+        float* outs[4];
+        size_t sizes[4];
+        jb.njobs = 4;
+        jb.zeros = h->zero_page;
+        int tiles = 0;
+        for (int dir = 0; dir < 2; ++dir) {
+            const int gi_idx = 2 * layer + dir;
+            const int ja = 2 * dir, jh = 2 * dir + 1;
+            jb.A[ja] = dgi_l + dir * 768; jb.lda[ja] = 1536; jb.B[ja] = xin; jb.ldb[ja] = in_sz; jb.N[ja] = in_sz; jb.shift[ja] = 0;
+            outs[ja] = g->gru_w_ih[gi_idx];
+            jb.A[jh] = dgh_l + dir * 768; jb.lda[jh] = 1536; jb.B[jh] = yout + dir * 256; jb.ldb[jh] = 512; jb.N[jh] = 256;
+            jb.shift[jh] = dir ? 1 : -1;
+            outs[jh] = g->gru_w_hh[gi_idx];
+        }
+        for (int j = 0; j < 4; ++j) {
+            jb.tile0[j] = tiles;
+            tiles += (768 / (tn2_dw ? TN2_BM : TN_BM_DW)) * ((jb.N[j] + TN_BN - 1) / TN_BN);
+            sizes[j] = (size_t)768 * jb.N[j];
+        }
+        jb.tile0[4] = tiles;
+        int tiles_chk, kchunk, nsplit;
+        size_t need;
+        tn_x6_plan(M, in_sz, &tiles_chk, &kchunk, &nsplit, &need);
+        size_t pos = 0;
+        for (int j = 0; j < 4; ++j) {
+            jb.slab[j] = p.slab + pos;
+            jb.slab_stride[j] = sizes[j];
+            pos += sizes[j] * nsplit;
+        }
+        if (tn2_dw)
+            hipLaunchKernelGGL(gemm_tn2_bf16x6_kernel<true>, dim3(tiles, nsplit), dim3(TN2_THREADS), tn2_lds_bytes(true), s_, jb, 768, M, kchunk, S);
+        else
+            hipLaunchKernelGGL((gemm_tn_bf16x6_kernel<true, TN_BM_DW>), dim3(tiles, nsplit), dim3(512), tn_lds_bytes(true, TN_BM_DW), s_, jb, 768, M, kchunk, S);
+        SlabJobs sj{};
+        for (int j = 0; j < 4; ++j) { sj.src[j] = jb.slab[j]; sj.out[j] = outs[j]; sj.n[j] = sizes[j]; }
+        hipLaunchKernelGGL(slab_reduce_jobs_kernel, dim3(grid_for(sizes[0]), 4), dim3(256), 0, s_, sj, nsplit);
+        return SIR_OK;
+    };
+
     if (part != SIR_BWD_CNN) {
     // ---- head: fc + attention pooling ----------------------------------------------------
     { SirProfScope prof(h, SIR_K_B_HEAD, st);
@@ -406,69 +484,19 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         const float* dy = layer ? p.dy1 : p.dy0;
         const float* gates = layer ? p.g1 : p.g0;
         const float* yout = layer ? p.y1 : p.y0;
-        const float* xin = layer ? y0in : p.x0;
+        float* dgi_l = layer ? p.dgi1 : p.dgi;
+        float* dgh_l = layer ? p.dgh1 : p.dgh;
         const int in_sz = layer ? 512 : 1024;
         { SirProfScope prof(h, layer ? SIR_K_B_GRU1 : SIR_K_B_GRU0, st);
         if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
-        rc = sir_launch_gru_bwd_pair(h, st, dy, gates, yout, w->gru_w_hh[2 * layer], w->gru_w_hh[2 * layer + 1], p.dgi, p.dgh, bsum_i, bsum_h,
+        rc = sir_launch_gru_bwd_pair(h, st, dy, gates, yout, w->gru_w_hh[2 * layer], w->gru_w_hh[2 * layer + 1], dgi_l, dgh_l, bsum_i, bsum_h,
                                      B, S);
         if (rc != SIR_OK) return rc;
         if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP;
         // bias gradients first: bsum_* alias the slab area used below
         hipLaunchKernelGGL(gru_bias_colsum_kernel, dim3(24, 2), dim3(256), 0, st, (const float*)bsum_i, (const float*)bsum_h, B,
                            g->gru_b_ih[2 * layer], g->gru_b_ih[2 * layer + 1], g->gru_b_hh[2 * layer], g->gru_b_hh[2 * layer + 1]); }
-        { SirProfScope prof(h, layer ? SIR_K_B_DW1 : SIR_K_B_DW0, st);
-        {
-            // all four weight-gradient GEMMs of the layer (2 directions x {W_ih, W_hh}) in one bf16x6 launch
-            if (!h->attr_tn) {
-                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<true, TN_BM_DW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn_lds_bytes(true, TN_BM_DW)));
-                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
-                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES_64));
-                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn2_bf16x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn2_lds_bytes(true)));
-                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn2_bf16x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn2_lds_bytes(false)));
-                SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn2_bf16x6_kernel<false, 0, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn2_lds_bytes(false, 64)));
-                h->attr_tn = true;
-            }
-            const bool tn2_dw = sir_tn2_mask() & 1;
-            TnJobs jb{};
-            float* outs[4];
-            size_t sizes[4];
-            jb.njobs = 4;
-            jb.zeros = h->zero_page;
-            int tiles = 0;
-            for (int dir = 0; dir < 2; ++dir) {
-                const int gi_idx = 2 * layer + dir;
-                const int ja = 2 * dir, jh = 2 * dir + 1;
-                jb.A[ja] = p.dgi + dir * 768; jb.lda[ja] = 1536; jb.B[ja] = xin; jb.ldb[ja] = in_sz; jb.N[ja] = in_sz; jb.shift[ja] = 0;
-                outs[ja] = g->gru_w_ih[gi_idx];
-                jb.A[jh] = p.dgh + dir * 768; jb.lda[jh] = 1536; jb.B[jh] = yout + dir * 256; jb.ldb[jh] = 512; jb.N[jh] = 256;
-                jb.shift[jh] = dir ? 1 : -1;
-                outs[jh] = g->gru_w_hh[gi_idx];
-            }
-            for (int j = 0; j < 4; ++j) {
-                jb.tile0[j] = tiles;
-                tiles += (768 / (tn2_dw ? TN2_BM : TN_BM_DW)) * ((jb.N[j] + TN_BN - 1) / TN_BN);
-                sizes[j] = (size_t)768 * jb.N[j];
-            }
-            jb.tile0[4] = tiles;
-            int tiles_chk, kchunk, nsplit;
-            size_t need;
-            tn_x6_plan(M, in_sz, &tiles_chk, &kchunk, &nsplit, &need);
-            size_t pos = 0;
-            for (int j = 0; j < 4; ++j) {
-                jb.slab[j] = p.slab + pos;
-                jb.slab_stride[j] = sizes[j];
-                pos += sizes[j] * nsplit;
-            }
-            if (tn2_dw)
-                hipLaunchKernelGGL(gemm_tn2_bf16x6_kernel<true>, dim3(tiles, nsplit), dim3(TN2_THREADS), tn2_lds_bytes(true), st, jb, 768, M, kchunk, S);
-            else
-                hipLaunchKernelGGL((gemm_tn_bf16x6_kernel<true, TN_BM_DW>), dim3(tiles, nsplit), dim3(512), tn_lds_bytes(true, TN_BM_DW), st, jb, 768, M, kchunk, S);
-            SlabJobs sj{};
-            for (int j = 0; j < 4; ++j) { sj.src[j] = jb.slab[j]; sj.out[j] = outs[j]; sj.n[j] = sizes[j]; }
-            hipLaunchKernelGGL(slab_reduce_jobs_kernel, dim3(grid_for(sizes[0]), 4), dim3(256), 0, st, sj, nsplit);
-        }
-        }
+        if (!defer_dw) { rc = launch_dw(layer, st); if (rc != SIR_OK) return rc; }
         // gradient wrt the layer input: dgi [M][1536] x [W_ih; W_ih_reverse] [1536][in]
         SirProfScope prof(h, layer ? SIR_K_B_DX1 : SIR_K_B_DX0, st);
         float* dxin = layer ? p.dy0 : p.dx0;
@@ -477,7 +505,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             jn.njobs = 1;
             jn.zeros = h->zero_page;
             if (layer == 1 && dropout_p > 0.0f) { jn.drop_p = dropout_p; jn.drop_seed = dropout_seed; }   // dy0 = mask * d(y0d)
-            jn.A[0] = p.dgi; jn.lda[0] = 1536;
+            jn.A[0] = dgi_l; jn.lda[0] = 1536;
             jn.B[0] = w->gru_w_ih[2 * layer]; jn.B2[0] = w->gru_w_ih[2 * layer + 1]; jn.brows[0] = 768; jn.ldb[0] = in_sz;
             jn.N[0] = in_sz; jn.shift[0] = 0;
             jn.slab[0] = dxin; jn.slab_stride[0] = 0;
@@ -509,8 +537,20 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         }
         KCHECK();
     }
+    if (defer_dw) {
+        // fork: the weight-gradient GEMMs of both layers behind the last dX (their slabs reuse the area the dX halves and the bias
+        // partial sums used on the caller's stream)
+        SIR_HIP_TRY(hipEventRecord(h->bwd_ev[0], st));
+        SIR_HIP_TRY(hipStreamWaitEvent(side, h->bwd_ev[0], 0));
+        for (int layer = 1; layer >= 0; --layer) { rc = launch_dw(layer, side); if (rc != SIR_OK) return rc; }
+        KCHECK();
+    }
     }
     if (part == SIR_BWD_HEAD_GRU) return SIR_OK;
+    if (two && !defer_dw) {                                  // SIR_BWD_CNN of the split form: the side stream starts behind the first half
+        SIR_HIP_TRY(hipEventRecord(h->bwd_ev[0], st));
+        SIR_HIP_TRY(hipStreamWaitEvent(side, h->bwd_ev[0], 0));
+    }
 
     // ---- conv3 block -------------------------------------------------------------------------
     if (!h->attr_wgrad) {
@@ -535,28 +575,32 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                                (const float*)p.dx0, scale + 96, shift + 96, smean + 96, sinv + 96, mdy + 96, mdyx + 96, p.dz3, B, 16,
                                d.wp2, 128, 8, d.wp3);
         }
+        if (two) {
+            SIR_HIP_TRY(hipEventRecord(h->bwd_ev[1], st));
+            SIR_HIP_TRY(hipStreamWaitEvent(side, h->bwd_ev[1], 0));
+        }
         {
-            SirProfScope prof(h, SIR_K_B_WGRAD3, st);
+            SirProfScope prof(h, SIR_K_B_WGRAD3, side);
             if ((sir_wgw_mask() & 2) && (size_t)B * 16 * d.wp2 * 128 * 4 < ((size_t)1 << 31)) {      // (32-bit buffer offsets)
                 // Winograd form: 16 products per tile and channel pair instead of 36 (wgrad_wino_bf16x6_kernel.h)
                 using Cfg3 = WgwCfg<64, 128>;
                 const int strips = wgrad_wino_strips(B, 16, d.wp2, Cfg3::TPS, Cfg3::groups);
-                hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<64, 128>), dim3(Cfg3::groups * strips), dim3(WGW_THREADS), Cfg3::lds_bytes, st,
+                hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<64, 128>), dim3(Cfg3::groups * strips), dim3(WGW_THREADS), Cfg3::lds_bytes, side,
                                    (const float*)p.dz3, (const float*)p.a2, p.slab, B, 16, d.wp2);
                 float* part = p.slab + (size_t)strips * 16 * 128 * 64;
-                hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((16 * 128 * 64 / 4 + 255) / 256), dim3(256), 0, st, (const float*)p.slab, strips,
+                hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((16 * 128 * 64 / 4 + 255) / 256), dim3(256), 0, side, (const float*)p.slab, strips,
                                    16 * 128 * 64 / 4, part);
-                hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((128 * 64 + 255) / 256), dim3(256), 0, st, (const float*)part, 64, 128, g->conv_w[2]);
+                hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((128 * 64 + 255) / 256), dim3(256), 0, side, (const float*)part, 64, 128, g->conv_w[2]);
             } else {
             const size_t ldsx = wgrad_x6_lds_bytes(64, 128, d.wp2);
             if (ldsx > 160 * 1024 || d.wp2 > wgrad_x6_max_w(128)) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
             const int nslab3 = d.wg3_blocks;                  // one slab per workgroup
-            hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<64, 128>), dim3(d.wg3_blocks), dim3(512), ldsx, st, (const float*)p.dz3,
+            hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<64, 128>), dim3(d.wg3_blocks), dim3(512), ldsx, side, (const float*)p.dz3,
                                (const float*)p.a2, p.slab, 16, d.wp2, d.wg3_rb);
             float* part = p.slab + (size_t)nslab3 * 9 * 128 * 64;
-            hipLaunchKernelGGL(wgrad_reduce_partial_kernel, dim3((9 * 128 * 64 / 4 + 255) / 256, WGR_PARTS), dim3(256), 0, st,
+            hipLaunchKernelGGL(wgrad_reduce_partial_kernel, dim3((9 * 128 * 64 / 4 + 255) / 256, WGR_PARTS), dim3(256), 0, side,
                                (const float*)p.slab, nslab3, 9 * 128 * 64 / 4, part);
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 128 * 64 + 255) / 256), dim3(256), 0, st, (const float*)part, WGR_PARTS, 64, 128,
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 128 * 64 + 255) / 256), dim3(256), 0, side, (const float*)part, WGR_PARTS, 64, 128,
                                g->conv_w[2]);
             }
         }
@@ -591,30 +635,35 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                                (const float*)p.da2, scale + 32, shift + 32, smean + 32, sinv + 32, mdy + 32, mdyx + 32, p.dz2, B, 32,
                                d.wp1, 64, 16, d.wp2);
         }
+        if (two) {
+            SIR_HIP_TRY(hipEventRecord(h->bwd_ev[2], st));
+            SIR_HIP_TRY(hipStreamWaitEvent(side, h->bwd_ev[2], 0));
+        }
         {
-            SirProfScope prof(h, SIR_K_B_WGRAD2, st);
+            SirProfScope prof(h, SIR_K_B_WGRAD2, side);
             if ((sir_wgw_mask() & 1) && (size_t)B * 32 * d.wp1 * 64 * 4 < ((size_t)1 << 31)) {
                 using Cfg2 = WgwCfg<32, 64>;
                 const int strips = wgrad_wino_strips(B, 32, d.wp1, Cfg2::TPS, Cfg2::groups);
-                hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<32, 64>), dim3(Cfg2::groups * strips), dim3(WGW_THREADS), Cfg2::lds_bytes, st,
+                hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<32, 64>), dim3(Cfg2::groups * strips), dim3(WGW_THREADS), Cfg2::lds_bytes, side,
                                    (const float*)p.dz2, (const float*)p.a1, p.slab, B, 32, d.wp1);
                 float* part = p.slab + (size_t)strips * 16 * 64 * 32;
-                hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((16 * 64 * 32 / 4 + 255) / 256), dim3(256), 0, st, (const float*)p.slab, strips,
+                hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((16 * 64 * 32 / 4 + 255) / 256), dim3(256), 0, side, (const float*)p.slab, strips,
                                    16 * 64 * 32 / 4, part);
-                hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((64 * 32 + 255) / 256), dim3(256), 0, st, (const float*)part, 32, 64, g->conv_w[1]);
+                hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((64 * 32 + 255) / 256), dim3(256), 0, side, (const float*)part, 32, 64, g->conv_w[1]);
             } else {
             const size_t ldsx = wgrad_x6_lds_bytes(32, 64, d.wp1);
             if (ldsx > 160 * 1024 || d.wp1 > wgrad_x6_max_w(64)) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
             const int nslab2 = d.wg2_blocks;                  // one slab per workgroup (its four k-split waves add up in LDS)
-            hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<32, 64>), dim3(d.wg2_blocks), dim3(512), ldsx, st, (const float*)p.dz2,
+            hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<32, 64>), dim3(d.wg2_blocks), dim3(512), ldsx, side, (const float*)p.dz2,
                                (const float*)p.a1, p.slab, 32, d.wp1, d.wg2_rb);
             float* part = p.slab + (size_t)nslab2 * 9 * 64 * 32;
-            hipLaunchKernelGGL(wgrad_reduce_partial_kernel, dim3((9 * 64 * 32 / 4 + 255) / 256, WGR_PARTS), dim3(256), 0, st,
+            hipLaunchKernelGGL(wgrad_reduce_partial_kernel, dim3((9 * 64 * 32 / 4 + 255) / 256, WGR_PARTS), dim3(256), 0, side,
                                (const float*)p.slab, nslab2, 9 * 64 * 32 / 4, part);
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 32 + 255) / 256), dim3(256), 0, st, (const float*)part, WGR_PARTS, 32, 64,
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 32 + 255) / 256), dim3(256), 0, side, (const float*)part, WGR_PARTS, 32, 64,
                                g->conv_w[1]);
             }
         }
+        if (two) SIR_HIP_TRY(hipEventRecord(h->bwd_ev[3], side));     // (the side stream's last launch)
         {
             SirProfScope prof(h, SIR_K_B_DGRAD2, st);
             hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 32, 4, 2, 2, 0, 4>), dim3(d.c2gx, 1, B), dim3(256), conv_ns_lds_bytes(4, 2), st,
@@ -641,6 +690,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                            w->conv_w[0], scale, smean, sinv, (double)B * 64 * T, g->bn_w[0], g->bn_b[0], g->conv_w[0]);
         KCHECK();
     }
+    if (two) SIR_HIP_TRY(hipStreamWaitEvent(st, h->bwd_ev[3], 0));   // join: every gradient is final on the caller's stream
     return SIR_OK;
 }
 

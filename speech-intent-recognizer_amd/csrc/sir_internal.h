@@ -87,6 +87,10 @@ struct sir_handle {
     struct XbufEntry { hipStream_t st; int kind; void* p; size_t cap, bytes; unsigned epoch; unsigned long long used; };
     XbufEntry xbufs[16];
     unsigned long long xbuf_clock;
+    // second stream of the training backward (SIR_BWD_STREAMS=1, model_train.hip): the off-chain weight-gradient launches; created on
+    // first use.  ev: 0 fork behind the GRU part, 1 / 2 dz3 / dz2 ready, 3 join
+    hipStream_t bwd_side;
+    hipEvent_t bwd_ev[4];
 };
 
 // granule buffer + launch epoch for a cluster kernel launched on `st`; allocates / grows / zeroes the buffer when needed.
@@ -162,6 +166,7 @@ static inline int sir_cluster_leave(sir_handle* h, hipStream_t st) {
 int sir_wino2_mask();
 int sir_wgw_mask();      // SIR_WGW: convolution weight gradients in Winograd form: bit 0 = conv2, bit 1 = conv3 (default 3)
 int sir_tn2_mask();      // SIR_TN2: GRU backward GEMMs on the producer / consumer kernel: bit 0 = dW, bit 1 = dX on 128-row tiles, bit 2 = dX on 64-row tiles, bit 3 = a dX that would take 64-row tiles runs as two K halves on 128-row tiles instead (default 15)
+int sir_bwd_streams();   // SIR_BWD_STREAMS: 1 = the backward's off-chain weight-gradient launches on a second, handle-owned stream (default 0)
 void sir_set_error(const char* fmt, ...);
 int sir_check_hip(hipError_t e, const char* what);
 
