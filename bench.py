@@ -75,6 +75,15 @@ BF16X6_KERNELS = {k for k in FLOPS_PER_UTT if "conv1" not in k}
 # csrc/conv_wino2_bf16x6_kernel.h (producer / consumer Winograd kernel; SIR_WINO2 selects the stages, default all three)
 WINOGRAD_KERNELS = {"conv2_mfma_bn_relu_pool", "conv3_mfma_bn_relu_pool", "train_conv2_fwd", "train_conv3_fwd", "bwd_conv3_dgrad",
                     "bwd_conv2_wgrad", "bwd_conv3_wgrad"}
+# kernel symbol behind each profile id of the inference leg (several ids may share one symbol: the roofline block reports the
+# largest single launch AND, as `by_symbol`, the symbol with the largest total time)
+KERNEL_SYMBOL = {
+    "feat_frames": "feat_utt_kernel<float,false>", "conv1_bn_relu_pool": "conv1_mfma_bn_relu_pool_kernel",
+    "conv2_mfma_bn_relu_pool": "conv3x3_wino2_bf16x6_kernel<32,64,0>", "conv3_mfma_bn_relu_pool": "conv3x3_wino2_bf16x6_kernel<64,128,1>",
+    "gemm_ih_l0": "gemm_nt (input projections)", "gemm_ih_l1": "gemm_nt (input projections)",
+    "gru_recurrence_l0": "gru_quad_kernel<false>", "gru_recurrence_l1": "gru_quad_kernel<false>",
+    "attention_pool_fc_argmax": "attention_pool_kernel",
+}
 FWD_FLOPS_PER_UTT = 400646144
 TRAIN_FLOPS_PER_UTT = 3 * FWD_FLOPS_PER_UTT                  # fwd + dgrad + wgrad convention: 1 201 938 432
 FEATURE_BYTES_PER_UTT = CLIP_LEN * 4 + 64 * T_PAD * 4       # 243 200 B (fp32 waveform in, features out)
@@ -198,6 +207,30 @@ def host_cpu_share(cap=16):
     return max(1, min(n, cap, int(os.environ.get("SIR_BENCH_CPU_THREADS", cap))))
 
 
+def host_cpu_info():
+    """What `cores` was derived from (VERDICT r3 bench hygiene): CPU model, logical CPUs, affinity-mask size, cgroup quota."""
+    info = {"os_cpu_count": os.cpu_count(), "cpu_model": None, "affinity_cpus": None, "cgroup_quota_cpus": None}
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    info["cpu_model"] = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        info["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        info["cgroup_quota_cpus"] = None if quota == "max" else round(int(quota) / int(period), 2)
+    except Exception:
+        pass
+    return info
+
+
 def pmc_traffic(kernel):
     """(HBM bytes per launch of `kernel`, source) from the newest COMMITTED rocprofv3 --pmc pass
     (profiles/*/pmc_traffic.json, written by devtools/gpu_pmc.sh + profiles/pmc_to_traffic.py) -- not measured in
@@ -264,7 +297,8 @@ def cpu_baseline(target_seconds=12.0):
     return {"value": round(all_rate, 2), "unit": "utterances/s", "cores": cores, "kind": "port",
             "sample": f"{reps} x (32 synthetic 3 s clips: torch.stft features one clip at a time + batch-8 "
                       f"fp32 forward + argmax), oracle/ restatement of the reference CPU path",
-            "single_thread_value": round(one_rate, 2)}, pred
+            "single_thread_value": round(one_rate, 2),
+            "host": dict(host_cpu_info(), cores_rule="min(affinity mask, cgroup CPU quota, 16): the box grants 16 CPUs per GPU")}, pred
 
 
 def cpu_train_baseline(cores, target_seconds=8.0):
@@ -391,6 +425,133 @@ class GpuSensors:
         return out
 
 
+class _TimedIter:
+    """Wraps a batch iterable: time of the first batch handed over and the clips it held (for a steady-state rate that leaves
+    the DataLoader's worker start-up out)."""
+
+    def __init__(self, it):
+        self.it, self.t_first, self.n_first, self.n = it, None, 0, 0
+
+    def __iter__(self):
+        for item in self.it:
+            k = int(item[0].size(0)) if item[0] is not None else 0
+            if self.t_first is None:
+                self.t_first, self.n_first = time.perf_counter(), k
+            self.n += k
+            yield item
+
+
+def dropin_epoch_leg(model, opt, fz, dev, step_rate, n_clips, batch=BATCH, workers=8):
+    """BASELINE configs[2] names `scripts/train.py drop-in, batch=256`: one EPOCH through the reference-shaped entry points over
+    a synthetic split of `n_clips` 3 s clips, per route, as utterances/s and as a fraction of the bare step rate (`train.value`):
+      dataloader        train_epoch() (train.py:72-118) over FSCIntentDataset + DataLoader(batch 256, num_workers 8, pin_memory)
+                        + collate_fn on a feature cache in the reference's file format (train.py:203-219, dataset.py:78-115)
+      hbm_feature_store the same cache staged once in HBM (sir_amd/feature_store.py), train_epoch() over its batches: train()'s
+                        default route
+      waveform_store    train_epoch_waveforms() over WaveformStore on the same clips (`fused_features: true`)
+    The split (clips, features, cache file, CSV) is built on the spot; building it is not timed."""
+    import shutil
+    import tempfile
+    import pandas as pd
+    from torch.utils.data import DataLoader
+    from sir_amd.feature_store import FeatureStore
+    from sir_amd.scripts import train as tr
+    from sir_amd.scripts.dataset import FSCIntentDataset
+    from sir_amd.waveform_store import WaveformStore
+    tmp = tempfile.mkdtemp(prefix="sir_dropin_")
+    try:
+        t_frames = 1 + CLIP_LEN // 512
+        pcm = torch.empty((n_clips, CLIP_LEN), dtype=torch.int16, device=dev)
+        host_feats = torch.empty((n_clips, 64, t_frames), dtype=torch.float32)
+        lengths = torch.full((batch,), CLIP_LEN, dtype=torch.int32, device=dev)
+        for start in range(0, n_clips, batch):
+            k = min(batch, n_clips - start)
+            clips = device_clips(k, CLIP_LEN, 99000 + start, dev)
+            pcm[start:start + k] = (clips * 32767.0).round().to(torch.int16)
+            host_feats[start:start + k] = fz(pcm[start:start + k], lengths[:k], t_pad=T_PAD)[:, :, :t_frames].cpu()
+        labels = torch.randint(0, NUM_CLASSES, (n_clips,), generator=torch.Generator().manual_seed(7))
+        names = [f"intent_{i:02d}" for i in range(NUM_CLASSES)]
+        paths = [os.path.join(tmp, "wav", f"clip{i:06d}.wav") for i in range(n_clips)]       # never opened: every clip is cached
+        csv = os.path.join(tmp, "train_data.csv")
+        pd.DataFrame({"path": paths, "label": [names[int(v)] for v in labels]}).to_csv(csv, index=False)
+        lm = os.path.join(tmp, "label_map.json")
+        with open(lm, "w") as f:
+            json.dump({n: i for i, n in enumerate(names)}, f)
+        cache_dir = os.path.join(tmp, "cache")
+        os.makedirs(cache_dir)
+        torch.save({p: {"features": host_feats[i], "label": names[int(labels[i])]} for i, p in enumerate(paths)},
+                   os.path.join(cache_dir, "train_data_features.pt"))
+        del host_feats
+        crit = torch.nn.CrossEntropyLoss()
+        aug_prob = 0.7                                   # configs/config.yaml:39
+        model.train()
+
+        def run(make_batches, epoch_fn):
+            """two epochs, the second one reported: (utt/s over the whole call, steady utt/s after the first batch, seconds)"""
+            best = None
+            for e in range(2):
+                it = _TimedIter(make_batches(e))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                epoch_fn(it)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                best = {"utts_per_s": round(it.n / (t1 - t0), 1), "epoch_s": round(t1 - t0, 4),
+                        "steady_utts_per_s": round((it.n - it.n_first) / max(t1 - it.t_first, 1e-9), 1),
+                        "first_batch_after_s": round(it.t_first - t0, 4), "clips": it.n}
+            best["frac_of_step_rate"] = round(best["utts_per_s"] / step_rate, 4)
+            best["steady_frac_of_step_rate"] = round(best["steady_utts_per_s"] / step_rate, 4)
+            return best
+
+        out = {"clips": n_clips, "batch": batch, "num_workers": workers, "augment_prob": aug_prob, "step_rate": step_rate,
+               "note": "fractions are of `train.value` (the bare step on HBM-resident clips); `steady_*` leaves out the time to the "
+                       "first batch (DataLoader worker start-up, paid every epoch as in the reference: no persistent workers)"}
+        # ---- route 1: the reference's own shape ----
+        t0 = time.perf_counter()
+        ds = FSCIntentDataset(csv, lm, is_training=True, augment_prob=aug_prob, cache_dir=cache_dir)
+        load_s = time.perf_counter() - t0
+
+        def loader(_e):
+            return DataLoader(ds, batch_size=batch, shuffle=True, num_workers=workers, collate_fn=tr.collate_fn, pin_memory=True)
+
+        lo = _TimedIter(loader(0))
+        t0 = time.perf_counter()
+        for mel, lab in lo:                              # loader alone: what the host side can deliver
+            mel = mel.to(dev, non_blocking=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        r = run(loader, lambda it: tr.train_epoch(model, it, opt, crit, dev))
+        r["loader_only_utts_per_s"] = round(lo.n / (t1 - t0), 1)
+        r["loader_only_steady_utts_per_s"] = round((lo.n - lo.n_first) / max(t1 - lo.t_first, 1e-9), 1)
+        r["cache_load_s"] = round(load_s, 3)
+        r["limit"] = ("host batch assembly (worker __getitem__ + collate_fn + pinned copy + H2D): the loader alone delivers "
+                      f"{r['loader_only_steady_utts_per_s']:.0f} utt/s" if r["loader_only_steady_utts_per_s"] < 1.15 * r["steady_utts_per_s"]
+                      else "the GPU step")
+        out["dataloader"] = r
+        del ds
+        # ---- route 2: the cache staged in HBM (train()'s default) ----
+        t0 = time.perf_counter()
+        store = FeatureStore(csv, lm, dev, cache_dir=cache_dir)
+        stage_s = time.perf_counter() - t0
+        r = run(lambda e: store.epoch_batches(batch, shuffle=True, seed=0, epoch=e, augment_prob=aug_prob),
+                lambda it: tr.train_epoch(model, it, opt, crit, dev))
+        r["stage_s"] = round(stage_s, 3)
+        r["limit"] = "the GPU step (one gather launch per batch, no host data path)"
+        out["hbm_feature_store"] = r
+        del store
+        # ---- route 3: raw waveforms in HBM, features inside the step ----
+        wstore = WaveformStore.from_tensors(pcm, torch.full((n_clips,), CLIP_LEN, dtype=torch.int32, device=dev), labels.to(dev))
+        cfg = {"augment_prob": aug_prob}
+        r = run(lambda e: wstore.epoch_batches(batch, shuffle=True, seed=0, epoch=e),
+                lambda it: tr.train_epoch_waveforms(model, it, opt, crit, dev, t_pad=T_PAD,
+                                                    augment=tr.make_waveform_augment(cfg, seed=0, epoch=0)))
+        r["limit"] = "the GPU step (feature kernel one batch ahead on a side stream)"
+        out["waveform_store"] = r
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -403,6 +564,9 @@ def main():
                     help="also time the training step with fused time-shift + noise + SpecAugment masks (default on)")
     ap.add_argument("--no-augment", dest="augment", action="store_false")
     ap.add_argument("--no-host-feed", action="store_true", help="skip the training leg fed from pinned host memory")
+    ap.add_argument("--no-dropin", action="store_true", help="N = 1 only: skip the `dropin_epoch` block (train_epoch() over the "
+                    "reference-shaped DataLoader route, the HBM feature store and the waveform store on a synthetic 16 384-clip split)")
+    ap.add_argument("--dropin-clips", type=int, default=int(os.environ.get("SIR_BENCH_DROPIN_CLIPS", "16384")))
     ap.add_argument("--train-steps", type=int, default=20)
     ap.add_argument("--sustain-seconds", type=float, default=6.0,
                     help="one extra region of pipelined inference steps of at least this many seconds (0 = skip): long enough "
@@ -728,6 +892,12 @@ def main():
                                       "h2d_GBs_needed": round(batch * CLIP_LEN * 2 * args.train_steps / h_el / 1e9, 2)}
             if rank == 0:
                 log(f"train leg fed from host memory: {train_info['host_fed']['value']} utt/s")
+        if world == 1 and not args.no_dropin:
+            try:
+                train_info["dropin_epoch"] = dropin_epoch_leg(model, opt, fz, dev, train_info["value"], args.dropin_clips, batch)
+            except Exception as e:                       # never lose the bench line to the extra block
+                train_info["dropin_epoch"] = {"error": f"{type(e).__name__}: {e}"}
+            log(f"dropin_epoch: {json.dumps(train_info['dropin_epoch'])}")
         model.eval()
     ops.check_status()                                          # a timed-out GRU recurrence would invalidate every figure
 
@@ -755,6 +925,20 @@ def main():
                         "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None,
                         "avg_launch_ms": round(d_ms, 5), "launches": dom_cnt[dominant],
                         "bytes_per_launch": FEATURE_BYTES_PER_UTT * batch}
+        # the kernel SYMBOL with the largest total time of a step (two launches of one symbol add up), beside the largest single launch
+        sym_ms, sym_flops = {}, {}
+        for k in infer_names:
+            if kernel_ms.get(k, 0.0) > 0.0 and k in KERNEL_SYMBOL:
+                sym_ms[KERNEL_SYMBOL[k]] = sym_ms.get(KERNEL_SYMBOL[k], 0.0) + kernel_ms[k]
+                sym_flops[KERNEL_SYMBOL[k]] = sym_flops.get(KERNEL_SYMBOL[k], 0) + FLOPS_PER_UTT.get(k, 0) * batch
+        if sym_ms:
+            top = max(sym_ms, key=lambda k: sym_ms[k])
+            tf = sym_flops[top] / (sym_ms[top] * 1e-3) / 1e12 if sym_flops[top] else None
+            roofline["by_symbol"] = {"symbol": top, "total_ms_per_step": round(sym_ms[top], 5),
+                                     "share_of_serial_step": round(sym_ms[top] / sum(sym_ms.values()), 4),
+                                     "achieved": round(tf, 3) if tf else None, "peak": round(PEAK_BF16X6_TFLOPS, 1), "unit": "TFLOP/s",
+                                     "frac": round(tf / PEAK_BF16X6_TFLOPS, 4) if tf else None,
+                                     "measured_in": "untimed HIP-event pass, one batch at a time (5 steps)"}
         feat_ms = kernel_ms.get("feat_frames", 0.0)      # ONE fused kernel since round 2 (profile id "feat_frames")
         gru = {}
         for k, algo in GRU_ALGO_BYTES.items():

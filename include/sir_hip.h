@@ -118,6 +118,22 @@ int sir_features_fwd(sir_handle* h, const void* wave, int wave_dtype, int64_t wa
                      float* db_out, void* workspace, size_t workspace_bytes, const sir_augment* aug,
                      void* stream);
 
+/* ---- batch assembly from an HBM-resident feature store -----------------------------------------
+ * sir_gather_features replaces, for a whole batch in one launch, what the reference does per item in DataLoader worker
+ * processes and then copies over PCIe: FSCIntentDataset.__getitem__ (scripts/dataset.py:78-115: cache lookup, SpecAugment,
+ * pad / trim -- the store rows are already padded to t_pad) + collate_fn's torch.stack (scripts/train.py:49-70) +
+ * mel.to(device) (scripts/train.py:86).  The split's cached features live in HBM once (sir_amd/feature_store.py: a few
+ * hundred MB of the 288 GB); a step's batch is a gather by index.
+ *   store     : [n_store][n_mels][t_pad] f32 (device), rows zero beyond each clip's frames
+ *   index     : device int64[batch], each in [0, n_store) (an index outside yields a zero row and SIR_EINVAL at the next
+ *               sir_check_status)
+ *   time_mask / freq_mask : optional device int32[batch][2] = {start, width} bands to zero (scripts/dataset.py:160-176,
+ *               drawn by the host as torchaudio's mask_along_axis does); NULL = none
+ *   out       : [batch][n_mels][t_pad] f32 */
+int sir_gather_features(sir_handle* h, const float* store, int64_t n_store, const int64_t* index, int batch,
+                        int n_mels, int t_pad, const int32_t* time_mask, const int32_t* freq_mask, float* out,
+                        void* stream);
+
 /* ---- model path ----------------------------------------------------------------------------
  * Device pointers to the reference's parameters/buffers under their state_dict names
  * (models/models.py:10-39): index 0..2 = conv1..3 / bn1..3; GRU index = 2*layer + reverse. */
@@ -224,7 +240,9 @@ int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, float* const 
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* nn.CrossEntropyLoss() (mean) of train.py:242/105: loss[0] = -mean log softmax(logits)[label];
- * dlogits (optional) = d loss / d logits * grad_scale. */
+ * dlogits (optional) = d loss / d logits * grad_scale.  As torch's default ignore_index, a label of -100 takes its row out of
+ * the loss, the gradient and the mean's divisor; any other label outside [0, num_classes) -- torch raises on it -- makes the
+ * loss NaN and is reported by sir_check_status (SIR_EINVAL). */
 int sir_ce_loss(sir_handle* h, const float* logits, const int64_t* labels, int batch, int num_classes,
                 float* loss, float* dlogits, float grad_scale, void* stream);
 

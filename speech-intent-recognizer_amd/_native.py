@@ -60,6 +60,8 @@ SIGNATURES = {
     "sir_resample_out_len": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "sir_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "sir_gather_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
     "sir_model_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "sir_model_workspace_offsets": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.c_int]),
     "sir_model_set_weights_version": (C.c_int, [C.c_void_p, C.c_uint64]),

@@ -79,6 +79,7 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     h->zero_page = nullptr; h->num_cus = 256;
     for (auto& x : h->xbufs) { x.st = nullptr; x.p = nullptr; x.kind = 0; x.cap = 0; x.bytes = 0; x.epoch = 0; x.used = 0; }
     h->xbuf_clock = 0;
+    h->xbuf_evictions = 0;
     h->bwd_side = nullptr;
     for (auto& e : h->bwd_ev) e = nullptr;
     h->cfg = *cfg;
@@ -298,6 +299,10 @@ static int check_status_impl(sir_handle* h, hipStream_t st, const char* who) {
         sir_set_error("%s: a GRU recurrence kernel timed out waiting for a peer workgroup of its cluster (status %u): the "
                       "logits / gradients produced since the last check are invalid", who, v);
         return SIR_ETIMEOUT;
+    }
+    if (v & 4u) {
+        sir_set_error("%s: sir_gather_features was given an index outside its store (status %u): those rows are zero", who, v);
+        return SIR_EINVAL;
     }
     sir_set_error("%s: sir_ce_loss saw a label outside [0, num_classes) (status %u): that step's loss is NaN and its "
                   "gradients are invalid (nn.CrossEntropyLoss raises on such a target)", who, v);

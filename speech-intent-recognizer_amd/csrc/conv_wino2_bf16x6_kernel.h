@@ -214,11 +214,13 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                 for (int rr = 0; rr < 3; ++rr) w2_read_row(rb + ra_rel[rr], q[rr][0], q[rr][1], q[rr][2], q[rr][3]);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (edge) {                                             // (one task in ~12: the halo column belongs to the neighbouring image)
-                    // a real branch (the asm keeps hipcc from turning it into 48 selects on the common path): multiply by 0 / 1
-                    const float k0 = z0 ? 0.0f : 1.0f, k3 = z3 ? 0.0f : 1.0f;
+                    // a real branch (the asm keeps hipcc from turning it into 24 selects on the common path).  SELECT zero, do not
+                    // multiply by it: the halo column was loaded from the neighbouring clip, and 0 * Inf / NaN of a corrupt
+                    // neighbour would leak into this clip's boundary columns (eval-mode samples are independent in the reference)
                     asm volatile("" ::: "memory");
+                    const w2_f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                    for (int rr = 0; rr < 3; ++rr) { q[rr][0] *= k0; q[rr][3] *= k3; }
+                    for (int rr = 0; rr < 3; ++rr) { q[rr][0] = z0 ? zero4 : q[rr][0]; q[rr][3] = z3 ? zero4 : q[rr][3]; }
                 }
                 // patch rows tR .. tR + 2 (row pair 0: i = 0: d0 - d2, i = 1: d1 + d2; pair 1 (rows 1,2,3): i = 2: d2 - d1, i = 3: d1 - d3).
                 // tR is wave-uniform: two straight-line copies under a branch (as one body hipcc computed both and selected: 32 v_cndmask)

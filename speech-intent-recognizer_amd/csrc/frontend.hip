@@ -184,3 +184,55 @@ extern "C" int sir_mix_to_mono(sir_handle* h, const void* pcm, int dtype, int ch
                            (long long)out_stride);
     return sir_check_hip(hipGetLastError(), "mono_kernel");
 }
+
+// ---- batch assembly from an HBM-resident feature store ------------------------------------------------------------------
+// out[b] = store[index[b]] with the SpecAugment bands of dataset.py:160-176 zeroed on the way: one pass, float4 per thread
+// (rows are t_pad floats, t_pad % 4 == 0).  A band {start, width} with width 0 is no band.
+namespace {
+__global__ __launch_bounds__(256) void gather_features_kernel(const float* __restrict__ store, const long long* __restrict__ index,
+                                                              long long n_store, int n_mels, int t_pad, const int* __restrict__ time_mask,
+                                                              const int* __restrict__ freq_mask, float* __restrict__ out,
+                                                              unsigned int* __restrict__ status) {
+    const int b = blockIdx.y;
+    long long src = index[b];
+    const bool bad = src < 0 || src >= n_store;
+    if (bad) {                                              // an index outside the store: zeros + the handle's status word (SIR_EINVAL at the next check)
+        if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_fetch_or(status, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        src = 0;
+    }
+    const int per = n_mels * t_pad / 4;
+    const float4* in4 = reinterpret_cast<const float4*>(store + (size_t)src * n_mels * t_pad);
+    float4* out4 = reinterpret_cast<float4*>(out + (size_t)b * n_mels * t_pad);
+    int t0 = 0, tw = 0, f0 = 0, fw = 0;
+    if (time_mask) { t0 = time_mask[2 * b]; tw = time_mask[2 * b + 1]; }
+    if (freq_mask) { f0 = freq_mask[2 * b]; fw = freq_mask[2 * b + 1]; }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < per; i += gridDim.x * 256) {
+        const int mel = (i * 4) / t_pad, t = (i * 4) - mel * t_pad;
+        float4 v = bad ? make_float4(0.f, 0.f, 0.f, 0.f) : in4[i];
+        if (mel >= f0 && mel < f0 + fw) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tw > 0) {
+            if (t >= t0 && t < t0 + tw) v.x = 0.0f;
+            if (t + 1 >= t0 && t + 1 < t0 + tw) v.y = 0.0f;
+            if (t + 2 >= t0 && t + 2 < t0 + tw) v.z = 0.0f;
+            if (t + 3 >= t0 && t + 3 < t0 + tw) v.w = 0.0f;
+        }
+        out4[i] = v;
+    }
+}
+}  // namespace
+
+extern "C" int sir_gather_features(sir_handle* h, const float* store, int64_t n_store, const int64_t* index, int batch, int n_mels,
+                                   int t_pad, const int32_t* time_mask, const int32_t* freq_mask, float* out, void* stream) {
+    if (!h || !store || !index || !out) { sir_set_error("sir_gather_features: NULL argument"); return SIR_EINVAL; }
+    if (batch <= 0 || batch > 65535 || n_store <= 0 || n_mels <= 0 || t_pad <= 0 || (t_pad & 3) != 0) {
+        sir_set_error("sir_gather_features: bad sizes (batch %d, store %lld, n_mels %d, t_pad %d: t_pad must be a multiple of 4)", batch,
+                      (long long)n_store, n_mels, t_pad);
+        return SIR_EINVAL;
+    }
+    const int per = n_mels * t_pad / 4;
+    int gx = (per + 255) / 256;
+    gx = gx > 16 ? 16 : gx;
+    hipLaunchKernelGGL(gather_features_kernel, dim3(gx, batch), dim3(256), 0, (hipStream_t)stream, store, (const long long*)index,
+                       (long long)n_store, n_mels, t_pad, (const int*)time_mask, (const int*)freq_mask, out, h->status);
+    return sir_check_hip(hipGetLastError(), "gather_features_kernel");
+}

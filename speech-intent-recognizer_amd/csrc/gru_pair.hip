@@ -31,7 +31,6 @@ int sir_launch_gru_bwd_pair(sir_handle* h, hipStream_t st, const float* dy, cons
     unsigned epoch = 0;
     void* xbuf = nullptr;
     if (sir_xbuf_acquire(h, st, 2, npairs * 2 * 2 * 2 * GP_BW * GP_UH * 8, 0xFFFFu, &xbuf, &epoch) != SIR_OK) {
-        sir_set_error("gru_bwd_pair: exchange buffer allocation failed");
         return SIR_EHIP;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(npairs * 2), 2), dim3(GP_THREADS), GBP_LDS_BYTES, st, dy, gates, y, whh0, whh1, dgi,

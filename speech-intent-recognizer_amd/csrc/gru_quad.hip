@@ -15,7 +15,6 @@ int sir_launch_gru_quad(sir_handle* h, hipStream_t st, bool save, const float* g
     unsigned epoch = 0;
     void* xbuf = nullptr;
     if (sir_xbuf_acquire(h, st, 1, (size_t)clusters * GQ_XBUF_PER_CLUSTER, 127u, &xbuf, &epoch) != SIR_OK) {
-        sir_set_error("gru_quad: exchange buffer allocation failed");
         return SIR_EHIP;
     }
     const dim3 grid(4 * (unsigned)clusters);

@@ -584,7 +584,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             if ((sir_wgw_mask() & 2) && (size_t)B * 16 * d.wp2 * 128 * 4 < ((size_t)1 << 31)) {      // (32-bit buffer offsets)
                 // Winograd form: 16 products per tile and channel pair instead of 36 (wgrad_wino_bf16x6_kernel.h)
                 using Cfg3 = WgwCfg<64, 128>;
-                const int strips = wgrad_wino_strips(B, 16, d.wp2, Cfg3::TPS, Cfg3::groups);
+                const int strips = wgrad_wino_strips(B, 16, d.wp2, Cfg3::TPS, Cfg3::groups, h->num_cus);
                 hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<64, 128>), dim3(Cfg3::groups * strips), dim3(WGW_THREADS), Cfg3::lds_bytes, side,
                                    (const float*)p.dz3, (const float*)p.a2, p.slab, B, 16, d.wp2);
                 float* part = p.slab + (size_t)strips * 16 * 128 * 64;
@@ -643,7 +643,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             SirProfScope prof(h, SIR_K_B_WGRAD2, side);
             if ((sir_wgw_mask() & 1) && (size_t)B * 32 * d.wp1 * 64 * 4 < ((size_t)1 << 31)) {
                 using Cfg2 = WgwCfg<32, 64>;
-                const int strips = wgrad_wino_strips(B, 32, d.wp1, Cfg2::TPS, Cfg2::groups);
+                const int strips = wgrad_wino_strips(B, 32, d.wp1, Cfg2::TPS, Cfg2::groups, h->num_cus);
                 hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<32, 64>), dim3(Cfg2::groups * strips), dim3(WGW_THREADS), Cfg2::lds_bytes, side,
                                    (const float*)p.dz2, (const float*)p.a1, p.slab, B, 32, d.wp1);
                 float* part = p.slab + (size_t)strips * 16 * 64 * 32;

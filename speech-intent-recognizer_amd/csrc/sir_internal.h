@@ -6,6 +6,8 @@
 #include <vector>
 #include "sir_hip.h"
 
+void sir_set_error(const char* fmt, ...);
+
 #define SIR_WAVE 64               // CDNA wavefront width (hard-coded, see cdna guide section 1)
 #define SIR_NFFT 1024
 #define SIR_HOP 512
@@ -87,6 +89,7 @@ struct sir_handle {
     struct XbufEntry { hipStream_t st; int kind; void* p; size_t cap, bytes; unsigned epoch; unsigned long long used; };
     XbufEntry xbufs[16];
     unsigned long long xbuf_clock;
+    unsigned long long xbuf_evictions;   // LRU evictions so far (each costs a device-synchronising hipFree + hipMalloc on the launch path)
     // second stream of the training backward (SIR_BWD_STREAMS=1, model_train.hip): the off-chain weight-gradient launches; created on
     // first use.  ev: 0 fork behind the GRU part, 1 / 2 dz3 / dz2 ready, 3 join
     hipStream_t bwd_side;
@@ -106,22 +109,23 @@ static inline int sir_xbuf_acquire(sir_handle* h, hipStream_t st, int kind, size
             if (x.used < e->used) e = &x;
         }
         if (e->p) {                                       // hipFree waits for the device: no launch can still be using it
-            if (hipFree(e->p) != hipSuccess) return SIR_EHIP;
+            ++h->xbuf_evictions;                          // (more than 16 live (stream, kind) pairs: every launch then frees + allocates)
+            if (hipFree(e->p) != hipSuccess) { sir_set_error("exchange buffer: hipFree of an evicted buffer failed"); return SIR_EHIP; }
             e->p = nullptr;
         }
         e->st = st; e->kind = kind; e->cap = 0; e->bytes = 0; e->epoch = 0;
     }
     if (bytes > e->cap) {
-        if (e->p && hipFree(e->p) != hipSuccess) return SIR_EHIP;
+        if (e->p && hipFree(e->p) != hipSuccess) { sir_set_error("exchange buffer: hipFree before growing failed"); return SIR_EHIP; }
         e->p = nullptr; e->cap = 0; e->bytes = 0;
         const size_t cap = sir_align_up_sz(bytes, (size_t)1 << 20);
-        if (hipMalloc(&e->p, cap) != hipSuccess) { e->p = nullptr; return SIR_EHIP; }
+        if (hipMalloc(&e->p, cap) != hipSuccess) { e->p = nullptr; sir_set_error("exchange buffer: hipMalloc of %zu bytes failed", cap); return SIR_EHIP; }
         e->cap = cap;
     }
     // new buffer, or more clusters than the PREVIOUS launch on it wrote: the extra granules are older than one epoch (after a
     // run of 128 smaller batches they would carry the current epoch again) -- zero.  Otherwise every granule that will be
     // polled was written by the previous launch, whose epoch differs.
-    if (bytes > e->bytes && hipMemsetAsync(e->p, 0, bytes, st) != hipSuccess) return SIR_EHIP;
+    if (bytes > e->bytes && hipMemsetAsync(e->p, 0, bytes, st) != hipSuccess) { sir_set_error("exchange buffer: hipMemsetAsync failed"); return SIR_EHIP; }
     e->bytes = bytes;
     e->epoch = (e->epoch + 1) & mask;
     e->used = ++h->xbuf_clock;
@@ -167,7 +171,7 @@ int sir_wino2_mask();
 int sir_wgw_mask();      // SIR_WGW: convolution weight gradients in Winograd form: bit 0 = conv2, bit 1 = conv3 (default 3)
 int sir_tn2_mask();      // SIR_TN2: GRU backward GEMMs on the producer / consumer kernel: bit 0 = dW, bit 1 = dX on 128-row tiles, bit 2 = dX on 64-row tiles, bit 3 = a dX that would take 64-row tiles runs as two K halves on 128-row tiles instead (default 15)
 int sir_bwd_streams();   // SIR_BWD_STREAMS: 1 = the backward's off-chain weight-gradient launches on a second, handle-owned stream (default 0)
-void sir_set_error(const char* fmt, ...);
+
 int sir_check_hip(hipError_t e, const char* what);
 
 #define SIR_HIP_TRY(expr)                                   \

@@ -247,7 +247,7 @@ static __global__ __launch_bounds__(256) void dropout_split3_kernel(const float*
 
 // ------------------------------------------------------------------------------------------
 // cross-entropy (mean) forward + gradient wrt logits:  loss = -mean_b log softmax(l_b)[y_b],
-// dlogits = (softmax - onehot) * grad_scale / B      (nn.CrossEntropyLoss(), train.py:242)
+// dlogits = (softmax - onehot) * grad_scale / (rows whose label is not ignore_index)      (nn.CrossEntropyLoss(), train.py:242)
 // single workgroup, deterministic reduction
 // ------------------------------------------------------------------------------------------
 template <int CMAX>
@@ -255,17 +255,30 @@ static __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __rest
                                                        int B, int C, float* __restrict__ loss, float* __restrict__ dlogits,
                                                        float grad_scale, unsigned int* status) {
     __shared__ float red[256];
+    __shared__ int cnt[256];
+    // nn.CrossEntropyLoss() has ignore_index = -100 by default: such a row contributes neither loss nor gradient and the mean is
+    // taken over the remaining rows (all rows ignored: 0 / 0 = NaN, as torch)
+    int nv = 0;
+    for (int b = threadIdx.x; b < B; b += 256) nv += labels[b] != -100ll ? 1 : 0;
+    cnt[threadIdx.x] = nv;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) cnt[threadIdx.x] += cnt[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float nvalid = (float)cnt[0];
     float acc = 0.0f;
     for (int b = threadIdx.x; b < B; b += 256) {
         // the row goes into registers with ALL its loads in flight (C <= CMAX, dispatched by the host): the per-class loops of
         // the first version waited for one dependent load after the other, 15 us for 256 x 31 logits
         const float* r = logits + (size_t)b * C;
-        // a label outside [0, C) (nn.CrossEntropyLoss raises on it; train.py:242): flag the handle's status word (bit 1 ->
+        // any OTHER label outside [0, C) (nn.CrossEntropyLoss raises on it; train.py:242): flag the handle's status word (bit 1 ->
         // SIR_EINVAL at the next sir_check_status) and make the loss NaN instead of reading out of bounds
         const long long yl = labels[b];
-        const bool bad = yl < 0 || yl >= (long long)C;
+        const bool ignored = yl == -100ll;
+        const bool bad = !ignored && (yl < 0 || yl >= (long long)C);
         if (bad) __hip_atomic_fetch_or(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int y = bad ? 0 : (int)yl;
+        const int y = (bad || ignored) ? 0 : (int)yl;
         float v[CMAX];
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) v[c] = c < C ? r[c] : 0.0f;
@@ -277,12 +290,12 @@ static __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __rest
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = expf(v[c] - mx); den += v[c]; }
         const float lse = mx + logf(den);
-        acc += bad ? __builtin_nanf("") : lse - ry;
+        acc += bad ? __builtin_nanf("") : (ignored ? 0.0f : lse - ry);
         if (dlogits) {
-            const float inv = 1.0f / den, gs = grad_scale / (float)B;
+            const float inv = 1.0f / den, gs = ignored ? 0.0f : grad_scale / nvalid;
 #pragma unroll
             for (int c = 0; c < CMAX; ++c)
-                if (c < C) dlogits[(size_t)b * C + c] = (v[c] * inv - (c == y ? 1.0f : 0.0f)) * gs;
+                if (c < C) dlogits[(size_t)b * C + c] = ignored ? 0.0f : (v[c] * inv - (c == y ? 1.0f : 0.0f)) * gs;
         }
     }
     red[threadIdx.x] = acc;
@@ -291,7 +304,7 @@ static __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __rest
         if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss[0] = red[0] / (float)B;
+    if (threadIdx.x == 0) loss[0] = red[0] / nvalid;
 }
 // ------------------------------------------------------------------------------------------
 // head backward: fc + attention pooling (models.py:63-67)

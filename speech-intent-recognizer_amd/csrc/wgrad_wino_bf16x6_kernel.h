@@ -35,9 +35,11 @@ template <int CIN, int COUT> struct WgwCfg {
     static constexpr size_t lds_bytes = 2 * (size_t)STAGE;                // 147,456 B for both shapes
     static constexpr int groups = 4 / KPW;                                // workgroups per strip
 };
-inline int wgrad_wino_strips(int B, int H, int W, int tps, int groups) {
+// `num_cus`: CUs of the device (sir_handle::num_cus); at most 256 workgroups in all, which is what the slab plan of
+// model_train.hip (64 strips of conv3, 128 of conv2) is sized for
+inline int wgrad_wino_strips(int B, int H, int W, int tps, int groups, int num_cus = 256) {
     const long long ntiles = (long long)B * (H / 2) * ((W + 1) / 2), nst = (ntiles + tps - 1) / tps;
-    const int cap = 256 / groups;                                           // one workgroup per CU
+    const int cap = (num_cus < 256 ? (num_cus < groups ? groups : num_cus) : 256) / groups;     // one workgroup per CU
     int s = nst < cap ? (int)nst : cap;
     if (s >= 8) s &= ~7;                                                    // multiples of 8: the XCD-aware order below
     return s < 1 ? 1 : s;

@@ -213,18 +213,29 @@ def train(args, config):
     # DataLoader workers).  `fused_features: true` trains from RAW waveforms staged once in HBM, features computed on
     # the GPU inside the step (BASELINE configs[2]); `waveform_augment: true` (implies fused_features) adds the
     # time-shift / noise augmentation of scripts/augment.py inside the feature kernel (configs[4]).
+    # `hbm_feature_cache` (default true): the cached-feature route keeps the split's cache in HBM (sir_amd/feature_store.py) and
+    # assembles each batch with one gather launch instead of DataLoader workers + a host -> device copy per step -- same files,
+    # same item semantics; false = the reference's DataLoader route, which at batch 256 delivers a fraction of what the training
+    # step consumes (bench.py `dropin_epoch`).
     wave_aug = bool(config.get("waveform_augment", False))
     fused = bool(config.get("fused_features", False)) or wave_aug
+    hbm_cache = bool(config.get("hbm_feature_cache", True)) and not fused
     train_store = None
     if fused:
         from sir_amd.waveform_store import WaveformStore
         train_store = WaveformStore(args.train_csv, args.label_map, device,
                                     sample_rate=int(config.get("sample_rate", 16000)))
-    train_dataset = train_store if fused else \
-        FSCIntentDataset(csv_path=args.train_csv, label_map_path=args.label_map, is_training=True,
-                         augment_prob=config.get("augment_prob", 0.5), use_cache=use_cache, cache_dir=cache_dir)
-    val_dataset = FSCIntentDataset(csv_path=args.val_csv, label_map_path=args.label_map, is_training=False,
-                                   use_cache=use_cache, cache_dir=cache_dir)
+    t_pad = int(config.get("mel_spec_length", MAX_LENGTH))
+    if hbm_cache:
+        from sir_amd.feature_store import FeatureStore
+        train_dataset = FeatureStore(args.train_csv, args.label_map, device, use_cache=use_cache, cache_dir=cache_dir, mel_spec_length=t_pad)
+        val_dataset = FeatureStore(args.val_csv, args.label_map, device, use_cache=use_cache, cache_dir=cache_dir, mel_spec_length=t_pad)
+    else:
+        train_dataset = train_store if fused else \
+            FSCIntentDataset(csv_path=args.train_csv, label_map_path=args.label_map, is_training=True,
+                             augment_prob=config.get("augment_prob", 0.5), use_cache=use_cache, cache_dir=cache_dir)
+        val_dataset = FSCIntentDataset(csv_path=args.val_csv, label_map_path=args.label_map, is_training=False,
+                                       use_cache=use_cache, cache_dir=cache_dir)
     if rank == 0:
         print(f"Datasets loaded - Train: {len(train_dataset)}, Val: {len(val_dataset)}")
 
@@ -233,10 +244,10 @@ def train(args, config):
     seed = int(config.get("seed", 0))
     train_sampler = train_ops.ShardSampler(len(train_dataset), rank, world, shuffle=True, seed=seed)
     val_sampler = train_ops.ShardSampler(len(val_dataset), rank, world, shuffle=False, pad=False)
-    train_loader = None if fused else DataLoader(train_dataset, batch_size=bs, sampler=train_sampler, num_workers=nw,
-                                                 collate_fn=collate_fn, pin_memory=True)
-    val_loader = DataLoader(val_dataset, batch_size=bs * 2, sampler=val_sampler, num_workers=nw,
-                            collate_fn=collate_fn, pin_memory=True)
+    train_loader = None if (fused or hbm_cache) else DataLoader(train_dataset, batch_size=bs, sampler=train_sampler, num_workers=nw,
+                                                                collate_fn=collate_fn, pin_memory=True)
+    val_loader = None if hbm_cache else DataLoader(val_dataset, batch_size=bs * 2, sampler=val_sampler, num_workers=nw,
+                                                   collate_fn=collate_fn, pin_memory=True)
 
     model = CNNAudioGRU(num_classes=config.get("num_labels", 31)).to(device)
     train_ops.broadcast_module_(model)             # identical initial weights / BN buffers on every rank
@@ -256,11 +267,17 @@ def train(args, config):
         if fused:
             batches = train_store.epoch_batches(bs, rank, world, shuffle=True, seed=seed, epoch=epoch)
             train_loss = train_epoch_waveforms(model, batches, optimizer, criterion, device,
-                                               t_pad=int(config.get("mel_spec_length", MAX_LENGTH)),
+                                               t_pad=t_pad,
                                                augment=make_waveform_augment(config, seed=seed + 977 * rank, epoch=epoch))
+        elif hbm_cache:
+            batches = train_dataset.epoch_batches(bs, rank, world, shuffle=True, seed=seed, epoch=epoch,
+                                                  augment_prob=float(config.get("augment_prob", 0.5)))
+            train_loss = train_epoch(model, batches, optimizer, criterion, device, None)
         else:
             train_sampler.set_epoch(epoch)
             train_loss = train_epoch(model, train_loader, optimizer, criterion, device, None)
+        if hbm_cache:
+            val_loader = val_dataset.epoch_batches(bs * 2, rank, world, shuffle=False, pad=False)
         val_loss, val_acc = validate(model, val_loader, criterion, device, None)
         if rank == 0:
             print(f"Train loss: {train_loss:.4f}, Val loss: {val_loss:.4f}, Val accuracy: {val_acc:.4f}")

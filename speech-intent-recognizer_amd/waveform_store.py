@@ -85,6 +85,19 @@ class WaveformStore:
         logger.info(f"staged {n} clips as {dtype} [{n}, {lmax}] on {self.device} "
                     f"({self.wave.numel() * self.wave.element_size() / 2 ** 20:.1f} MiB)")
 
+    @classmethod
+    def from_tensors(cls, wave, lengths, labels, sample_rate=16000):
+        """A store over clips that already sit on the device (bench.py: synthetic clips generated on the GPU)."""
+        _native.require_hip(wave, lengths, labels)
+        self = cls.__new__(cls)
+        self.device = wave.device
+        self.sample_rate = sample_rate
+        self.wave = wave.contiguous()
+        self.lengths = lengths.to(torch.int32)
+        self.labels = labels.to(torch.int64)
+        self.host_lengths = self.lengths.cpu()
+        return self
+
     def __len__(self):
         return int(self.wave.shape[0])
 

@@ -23,3 +23,9 @@ def model_golden():
 def features_golden():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "features_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def traj_golden():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "train_traj_golden.npz"))

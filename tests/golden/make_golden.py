@@ -6,6 +6,9 @@
   (imported from /root/reference, torch-only) on seeded inputs/weights -- logits, argmax,
   one training step (loss, sampled grads, BN running stats, sampled post-Adam params).
   These pin ``oracle/model_ref.py``.
+* ``train_traj_golden.npz``: a K = 10 step Adam trajectory of the REFERENCE model on ``x_train8`` (``gru.dropout = 0``): loss
+  and logits norm per step, sampled parameters and BN running statistics after step 10 ("matched
+  accuracy" over more than one step).
 * ``features_golden.npz``: outputs of ``oracle/features_ref.py`` (float32 torch.stft path and the
   float64 numpy path).  torchaudio is not installed, so these are NOT reference outputs:
   feature parity is "unpinned" (see oracle/__init__.py).
@@ -96,6 +99,52 @@ def make_model_golden():
     print("model_golden.npz:", len(out), "arrays; eval8 argmax", out["eval8_argmax"], "loss", out["train8_loss"])
 
 
+TRAJ_STEPS = 10
+
+
+def make_trajectory_golden():
+    """K Adam steps (train.py:90-107: zero_grad, forward, CrossEntropyLoss, backward, step; Adam as train.py:246-250 at the shipped
+    lr / weight decay) of the reference's own CNNAudioGRU on the SAME batch ``x_train8``; one torch thread so that the file
+    regenerates bit for bit whatever the host's core count."""
+    sys.path.insert(0, "/root/reference")
+    from models.models import CNNAudioGRU  # the reference itself
+
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        sd = synth.synth_state_dict(31, seed=0)
+        inp = cases.model_inputs()
+        model = CNNAudioGRU(31)
+        model.load_state_dict(sd)
+        model.train()
+        model.gru.dropout = 0.0
+        opt = torch.optim.Adam(model.parameters(), lr=LR, weight_decay=WEIGHT_DECAY)
+        crit = torch.nn.CrossEntropyLoss()
+        losses, lnorms = [], []
+        for _ in range(TRAJ_STEPS):
+            opt.zero_grad(set_to_none=True)
+            logits = model(inp["x_train8"])
+            loss = crit(logits, inp["y_train8"])
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+            lnorms.append(logits.detach().double().norm().item())
+        out = {"steps": np.int32(TRAJ_STEPS), "loss": np.asarray(losses, np.float32), "logits_norm": np.asarray(lnorms, np.float32),
+               "final_logits": logits.detach().numpy()}
+        for name, p in model.named_parameters():
+            flat = p.detach().flatten()
+            idx = cases.sample_indices(name, flat.numel())
+            out[f"param_samp/{name}"] = flat[idx].numpy()
+            out[f"param_delta_norm/{name}"] = np.float32((p.detach() - sd[name]).double().norm().item())
+        for i in (1, 2, 3):
+            out[f"bn{i}.running_mean"] = getattr(model, f"bn{i}").running_mean.numpy()
+            out[f"bn{i}.running_var"] = getattr(model, f"bn{i}").running_var.numpy()
+    finally:
+        torch.set_num_threads(nthr)
+    np.savez_compressed(os.path.join(HERE, "train_traj_golden.npz"), **out)
+    print("train_traj_golden.npz:", len(out), "arrays; losses", [f"{v:.5f}" for v in losses])
+
+
 def make_features_golden():
     out = {}
     for name, wave in cases.feature_cases().items():
@@ -112,4 +161,5 @@ def make_features_golden():
 
 if __name__ == "__main__":
     make_model_golden()
+    make_trajectory_golden()
     make_features_golden()

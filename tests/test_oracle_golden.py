@@ -62,6 +62,30 @@ def test_model_train_step_matches_reference(sd, model_golden):
                                    rtol=1e-5, atol=1e-6)
 
 
+def test_model_ten_step_trajectory_matches_reference(sd, traj_golden):
+    """The functional restatement (explicit BN, explicit GRU cell loop, CE, restated Adam) follows the REFERENCE model's own
+    10-step Adam trajectory on a fixed batch: loss of every step, sampled parameters and BN running statistics at the end."""
+    inp = cases.model_inputs()
+    k = int(traj_golden["steps"])
+    cur = {n: v.clone() for n, v in sd.items()}
+    ms = {n: torch.zeros_like(sd[n]) for n in model_ref.PARAM_KEYS}
+    vs = {n: torch.zeros_like(sd[n]) for n in model_ref.PARAM_KEYS}
+    for step in range(1, k + 1):
+        loss, grads, new_stats, _ = model_ref.loss_and_grads(cur, inp["x_train8"], inp["y_train8"])
+        assert abs(loss.item() - float(traj_golden["loss"][step - 1])) < 2e-5, step
+        for n in model_ref.PARAM_KEYS:
+            cur[n], ms[n], vs[n] = model_ref.adam_step(cur[n], grads[n], ms[n], vs[n], step=step, lr=cases.LR,
+                                                       weight_decay=cases.WEIGHT_DECAY)
+        cur.update(new_stats)
+    for n in model_ref.PARAM_KEYS:
+        idx = cases.sample_indices(n, cur[n].numel())
+        d = np.abs(cur[n].flatten()[idx].numpy() - traj_golden[f"param_samp/{n}"])
+        assert np.quantile(d, 0.9) <= 2e-6 * k and d.max() <= 2.1 * cases.LR * k, (n, d.max())
+    for i in (1, 2, 3):
+        np.testing.assert_allclose(cur[f"bn{i}.running_mean"].numpy(), traj_golden[f"bn{i}.running_mean"], rtol=1e-4, atol=1e-6 * k)
+        np.testing.assert_allclose(cur[f"bn{i}.running_var"].numpy(), traj_golden[f"bn{i}.running_var"], rtol=1e-4, atol=1e-6 * k)
+
+
 def test_features_f32_reproduce_committed(features_golden):
     for name, wave in cases.feature_cases().items():
         st = features_ref.extract_features_f32(wave, stages=True)

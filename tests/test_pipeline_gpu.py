@@ -98,6 +98,47 @@ def test_precompute_dataset_train_evaluate(tmp_path):
     assert 0.0 <= acc <= 1.0
     assert os.path.exists(os.path.join(cfg["save_path"], "evaluation_results", "classification_report.txt"))
 
+    # ---- parity THROUGH the entry points (evaluate.py:79-86, train.py:120-155): the oracle on the same checkpoint and the same
+    # cached features must give the same predicted indices -- hence identical correct / total counts -- and the same loss
+    from oracle import model_ref
+    from sir_amd.models.models import CNNAudioGRU
+    from torch.utils.data import DataLoader
+    sd_ck = {k: v.cpu() for k, v in torch.load(ckpt).items()}
+    allp = tmp_path / "all_data.csv"
+    pd.DataFrame(rows).to_csv(allp, index=False)            # all 24 clips (two of them fail -> zero features, dataset.py:156-158)
+    pf.precompute_dataset_features(str(allp), cache_dir)
+
+    def oracle_on(csv_path, batch):
+        ds_ = FSCIntentDataset(csv_path, str(lm), is_training=False, cache_dir=cache_dir)
+        items = [ds_[i] for i in range(len(ds_))]
+        mel = torch.stack([m for m, _ in items])
+        lab = torch.tensor([l for _, l in items])
+        with torch.no_grad():
+            logits = model_ref.forward(sd_ck, mel)
+        losses = [torch.nn.functional.cross_entropy(logits[i:i + batch], lab[i:i + batch]).item() for i in range(0, len(lab), batch)]
+        return logits.argmax(1), lab, float(np.mean(losses)), logits
+
+    for csv_path in (csvs["test"], str(allp)):
+        pred_o, lab_o, _, logits_o = oracle_on(csv_path, cfg["batch_size"])
+        acc_e = ev.evaluate(types.SimpleNamespace(test_csv=csv_path, label_map=str(lm), model_path=ckpt), cfg)
+        n = len(lab_o)
+        assert round(acc_e * n) == int((pred_o == lab_o).sum()), (csv_path, acc_e)      # identical counts
+        model = CNNAudioGRU(31)
+        model.load_state_dict(sd_ck)
+        model = model.cuda()
+        ds_ = FSCIntentDataset(csv_path, str(lm), is_training=False, cache_dir=cache_dir)
+        loader = DataLoader(ds_, batch_size=cfg["batch_size"], shuffle=False, num_workers=0, collate_fn=tr.collate_fn)
+        preds, labels = ev.predict_loader(model, loader, torch.device("cuda"))
+        assert (torch.as_tensor(preds) == pred_o).all() and (torch.as_tensor(labels) == lab_o).all()      # identical indices
+        vloader = DataLoader(ds_, batch_size=2 * cfg["batch_size"], shuffle=False, num_workers=0, collate_fn=tr.collate_fn)
+        _, _, loss_o, _ = oracle_on(csv_path, 2 * cfg["batch_size"])
+        vloss, vacc = tr.validate(model, vloader, torch.nn.CrossEntropyLoss(), torch.device("cuda"))
+        assert round(vacc * n) == int((pred_o == lab_o).sum()) and abs(vacc - acc_e) < 1e-12
+        assert abs(vloss - loss_o) <= 1e-5, (vloss, loss_o)
+        top2 = logits_o.sort(1).values
+        print(f"{os.path.basename(csv_path)}: {n} clips, {len(set(pred_o.tolist()))} predicted classes, min top-2 margin "
+              f"{(top2[:, -1] - top2[:, -2]).min():.3e}, accuracy {acc_e:.4f}, val loss {vloss:.6f} (oracle {loss_o:.6f})")
+
 
 def _ddp_worker(rank, world, port, out_dir):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",

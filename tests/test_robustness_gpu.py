@@ -111,6 +111,25 @@ def test_out_of_range_label_is_reported_not_read_out_of_bounds(sd):
     ops.check_status()
 
 
+def test_ignore_index_rows_follow_torch():
+    """nn.CrossEntropyLoss() (train.py:242) has ignore_index = -100: such rows leave the loss, the gradient and the divisor."""
+    torch.manual_seed(3)
+    lg = torch.randn(9, 31)
+    labels = torch.tensor([0, -100, 30, 5, -100, 7, 1, 2, -100])
+    a = lg.clone().to(DEV).requires_grad_(True)
+    b = lg.clone().requires_grad_(True)
+    la = train_ops.fused_cross_entropy(a, labels.to(DEV))
+    lb = torch.nn.functional.cross_entropy(b, labels)
+    la.backward()
+    lb.backward()
+    assert abs(la.item() - lb.item()) < 1e-6
+    assert (a.grad.cpu() - b.grad).abs().max() < 1e-7 and (a.grad[1] == 0).all() and (a.grad[8] == 0).all()
+    ops.check_status()                                   # -100 is not an error
+    allign = train_ops.fused_cross_entropy(a.detach(), torch.full((9,), -100, device=DEV))
+    assert torch.isnan(allign)                           # 0 / 0, as torch
+    ops.check_status()
+
+
 _TEARDOWN = """
 import os, sys, gc
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests", "golden"))

@@ -179,6 +179,48 @@ def test_train_step_matches_reference_golden(sd, model_golden):
         np.testing.assert_allclose(bn.running_var.cpu().numpy(), model_golden[f"bn{i}.running_var"], rtol=1e-4, atol=1e-6)
 
 
+def test_ten_step_trajectory_matches_reference_golden(sd, traj_golden):
+    """K = 10 Adam steps on the same batch against the trajectory the REFERENCE's own CNNAudioGRU + torch.optim.Adam produced
+    (tests/golden/make_golden.py::make_trajectory_golden; train.py:90-107, :246-250; gru.dropout = 0): the loss of every step
+    within 1e-4 abs, the sampled parameters after step 10 within the one-step Adam bound of the test above scaled by K, BN
+    running statistics as after one step.  ("matched accuracy" over more than one step: the dataset is absent, so the
+    reference's own trajectory on a fixed batch is the available form.)"""
+    inp = cases.model_inputs()
+    k = int(traj_golden["steps"])
+    m = _model(sd)
+    opt = FusedAdam(m.parameters(), lr=cases.LR, weight_decay=cases.WEIGHT_DECAY)
+    x, y = inp["x_train8"].to(DEV), inp["y_train8"].to(DEV)
+    losses = []
+    for _ in range(k):
+        opt.zero_grad(set_to_none=True)
+        logits = m(x)
+        loss = train_ops.fused_cross_entropy(logits, y)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    torch.cuda.synchronize()
+    dl = np.abs(np.asarray(losses, np.float32) - traj_golden["loss"])
+    print("trajectory: max |loss - reference| per step", dl.max(), "losses", [f"{v:.5f}" for v in losses])
+    assert dl.max() <= 1e-4, dl
+    assert losses[-1] < losses[0] - 0.5                              # (the reference drops 3.50 -> 2.62 on this batch)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), traj_golden["final_logits"], rtol=0, atol=2e-4)
+    worst = 0.0
+    for name, p in m.named_parameters():
+        flat = p.detach().cpu().flatten()
+        idx = cases.sample_indices(name, flat.numel())
+        d = np.abs(flat[idx].numpy() - traj_golden[f"param_samp/{name}"])
+        worst = max(worst, float(d.max()))
+        assert np.quantile(d, 0.9) <= 2e-6 * k and d.max() <= 2.1 * cases.LR * k, (name, np.quantile(d, 0.9), d.max())
+        dn = (p.detach().cpu() - sd[name]).double().norm().item()
+        assert abs(dn - float(traj_golden[f"param_delta_norm/{name}"])) <= 0.02 * float(traj_golden[f"param_delta_norm/{name}"]) + 1e-7, name
+    print("trajectory: worst sampled parameter difference after", k, "steps:", worst)
+    for i in (1, 2, 3):
+        bn = getattr(m, f"bn{i}")
+        np.testing.assert_allclose(bn.running_mean.cpu().numpy(), traj_golden[f"bn{i}.running_mean"], rtol=1e-4, atol=1e-6 * k)
+        np.testing.assert_allclose(bn.running_var.cpu().numpy(), traj_golden[f"bn{i}.running_var"], rtol=1e-4, atol=1e-6 * k)
+        assert int(bn.num_batches_tracked) == k
+
+
 def test_adam_kernel_vs_oracle_over_steps():
     torch.manual_seed(0)
     ps = [torch.randn(n) for n in (5, 4097, 70000)]
