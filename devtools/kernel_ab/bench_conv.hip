@@ -260,7 +260,7 @@ static void load_loop(double seconds) {
 }
 
 // Second-generation Winograd kernel (conv_wino2_bf16x6_kernel.h) against the direct kernel: same input, same weights.
-//   MODE 0: pooled NHWC, 1: pooled GRU layout + bf16x3 planes, 2: raw + statistics, 3: raw (data gradient: DGRAD weights)
+//   MODE 0: pooled NHWC, 1: pooled GRU layout + f16x2 planes, 2: raw + statistics, 3: raw (data gradient: DGRAD weights)
 template <int CIN, int COUT, int PR, int PC, int MODE, bool DGRAD, int MINB>
 static void run_wino2(const char* name, int B, int H, int W, int reps = 60) {
     const int Hp = H / 2, Wp = W / 2;
@@ -324,10 +324,10 @@ static void run_wino2(const char* name, int B, int H, int W, int reps = 60) {
             // planes of slightly different floats differ in their low parts: compare the reconstructed values
             double dp = 0;
             for (size_t i = 0; i < nout; ++i) {
-                auto f = [](unsigned short u) { unsigned v = (unsigned)u << 16; float x; memcpy(&x, &v, 4); return (double)x; };
-                dp = fmax(dp, fabs(f(p1[i]) + f(p1[nout + i]) + f(p1[2 * nout + i]) - f(p2[i]) - f(p2[nout + i]) - f(p2[2 * nout + i])));
+                auto f = [](unsigned short u) { _Float16 hv; memcpy(&hv, &u, 2); return (double)(float)hv; };
+                dp = fmax(dp, fabs(f(p1[i]) + f(p1[nout + i]) / 2048.0 - f(p2[i]) - f(p2[nout + i]) / 2048.0));
             }
-            printf("  bf16x3 planes (hi + mid + lo): max difference %.3e\n", dp);
+            printf("  f16x2 planes (hi + lo / 2^11) of the following GEMM's operand: max difference %.3e\n", dp);
         }
         if (MODE == 2) {
             const size_t n1 = (size_t)gd.x * gd.y * B, n2 = wino2_stat_blocks(B, H, W, 256);
@@ -354,6 +354,35 @@ static void run_wino2(const char* name, int B, int H, int W, int reps = 60) {
         const float tp1 = time_us(st, reps, [&] { CK_((launch_conv_wino2<CIN, COUT, MODE, 0, 1>(st, &atp[0], dxr[rot++ & 3], wpw, ds, dt, o2, B, H, W, MODE == 1 ? (float2*)pl2 : st2, dzero))); });
         const float tp2 = time_us(st, reps, [&] { CK_((launch_conv_wino2<CIN, COUT, MODE, 0, 3>(st, &atp[1], dxr[rot++ & 3], wpw, ds, dt, o2, B, H, W, MODE == 1 ? (float2*)pl2 : st2, dzero))); });
         printf("  rotating inputs: direct %.1f us (%.1f TF)   wino2 %.1f us (%.1f TF algorithmic); producers at s_setprio 1: %.1f, 3: %.1f us\n", t1, gf * 1e3 / t1, t2, gf * 1e3 / t2, tp1, tp2);
+        // round 4: the same kernel on the f16x3 arithmetic (F16 = true; weights from prep_conv_w(T)_wino_f16x3)
+        {
+            unsigned short* wph; CK_(hipMalloc(&wph, (size_t)COUT * CIN * 16 * 6));
+            unsigned int* dstat; CK_(hipMalloc(&dstat, 256)); CK_(hipMemset(dstat, 0, 256));
+            if (DGRAD) hipLaunchKernelGGL(prep_conv_wT_wino_f16x3_kernel, dim3((CIN * 16 * COUT + 255) / 256), dim3(256), 0, st, (const float*)dw, wph, COUT, CIN, dstat);
+            else hipLaunchKernelGGL(prep_conv_w_wino_f16x3_kernel, dim3((CIN * 16 * COUT + 255) / 256), dim3(256), 0, st, (const float*)dw, wph, CIN, COUT, dstat);
+            bool ah = false;
+            auto wino2h = [&](const float* in) {
+                CK_((launch_conv_wino2<CIN, COUT, MODE, 0, 3, true>(st, &ah, in, wph, ds, dt, o2, B, H, W, MODE == 1 ? (float2*)pl2 : st2, dzero))); };
+            CK_(hipMemsetAsync(o2, 0, nout * 4, st));
+            direct(dx); wino2h(dx);
+            CK_(hipStreamSynchronize(st));
+            std::vector<float> h1(nout), h2(nout);
+            CK_(hipMemcpy(h1.data(), o1, nout * 4, hipMemcpyDeviceToHost)); CK_(hipMemcpy(h2.data(), o2, nout * 4, hipMemcpyDeviceToHost));
+            double d = 0; size_t bad = 0;
+            for (size_t i = 0; i < nout; ++i) { const double e = fabs((double)h1[i] - h2[i]); d = fmax(d, e); bad += e > 1e-4; }
+            const float th = time_us(st, reps, [&] { wino2h(dxr[rot++ & 3]); });
+            auto koh = [&](auto kc) {
+                bool at = false;
+                return time_us(st, reps, [&] { CK_((launch_conv_wino2<CIN, COUT, MODE, decltype(kc)::value, 3, true>(st, &at, dx, wph, ds, dt, o2, B, H, W, MODE == 1 ? (float2*)pl2 : st2, dzero))); });
+            };
+            using std::integral_constant;
+            printf("  f16x3 arithmetic: max |direct(bf16x6) - wino2(f16x3)| = %.3e, %zu elements off by > 1e-4; rotating inputs %.1f us (%.1f TF algorithmic, bf16x6 %.1f us)\n",
+                   d, bad, th, gf * 1e3 / th, t2);
+            printf("  f16x3 knock-outs (one cached input): full %.1f, no DMA %.1f, no transform %.1f, no MFMA %.1f, no epilogue %.1f, only barriers+epilogue %.1f, weights once %.1f us\n",
+                   koh(integral_constant<int, 32>{}), koh(integral_constant<int, 2>{}), koh(integral_constant<int, 4>{}), koh(integral_constant<int, 8>{}),
+                   koh(integral_constant<int, 16>{}), koh(integral_constant<int, 14>{}), koh(integral_constant<int, 64>{}));
+            (void)hipFree(wph); (void)hipFree(dstat);
+        }
         for (int k = 0; k < 4; ++k) (void)hipFree(dxr[k]);
         // phase stamps of workgroup 0, second task (cycles relative to the first stamp): group A | group B
         bool attr2 = false;

@@ -49,6 +49,11 @@ int sir_tn2_mask() {
     return m;
 }
 
+int sir_f16_mask() {
+    static const int m = getenv("SIR_F16") ? atoi(getenv("SIR_F16")) : 3;
+    return m;
+}
+
 int sir_bwd_streams() {
     static const int m = getenv("SIR_BWD_STREAMS") ? atoi(getenv("SIR_BWD_STREAMS")) : 0;
     return m;
@@ -299,6 +304,11 @@ static int check_status_impl(sir_handle* h, hipStream_t st, const char* who) {
         sir_set_error("%s: a GRU recurrence kernel timed out waiting for a peer workgroup of its cluster (status %u): the "
                       "logits / gradients produced since the last check are invalid", who, v);
         return SIR_ETIMEOUT;
+    }
+    if (v & 8u) {
+        sir_set_error("%s: a transformed convolution weight is outside the f16x3 path's range (|U| >= 32, status %u): the outputs "
+                      "computed from the clamped value are invalid", who, v);
+        return SIR_EINVAL;
     }
     if (v & 4u) {
         sir_set_error("%s: sir_gather_features was given an index outside its store (status %u): those rows are zero", who, v);

@@ -61,6 +61,8 @@ __device__ __forceinline__ void split3_rows(const float* __restrict__ in, int ld
         *reinterpret_cast<uint4*>(out + 2 * plane + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
 }
+#include "f16_split.h"
+
 static __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ in, int ld_in, unsigned short* __restrict__ out,
                                                              size_t rows, int K) {
     split3_rows(in, ld_in, out, rows, K, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
@@ -587,15 +589,14 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_bf16x6_ns_kernel(
                 const float4 v4 = make_float4(pooled[0], pooled[1], pooled[2], pooled[3]);
                 *reinterpret_cast<float4*>(o) = v4;
                 if (stats) {
-                    // OUT_MODE 1 only: `stats` carries the bf16x3 plane buffer [3][B * Wp][COUT * Hp] of the following
+                    // OUT_MODE 1 only: `stats` carries the f16x2 plane buffer [2][B * Wp][COUT * Hp] (f16_split.h) of the following
                     // GEMM's A operand, written here so that no separate split pass has to re-read the activations
                     unsigned short* planes = reinterpret_cast<unsigned short*>(stats);
                     const size_t plane = (size_t)gridDim.z * Wp * (COUT * Hp);
-                    uint2 hh, mm, ll;
-                    split3_quad(v4, hh, mm, ll);
+                    uint2 hh, ll;
+                    split2h_quad(v4, hh, ll);
                     *reinterpret_cast<uint2*>(planes + oidx) = hh;
-                    *reinterpret_cast<uint2*>(planes + plane + oidx) = mm;
-                    *reinterpret_cast<uint2*>(planes + 2 * plane + oidx) = ll;
+                    *reinterpret_cast<uint2*>(planes + plane + oidx) = ll;
                 }
             } else {
 #pragma unroll

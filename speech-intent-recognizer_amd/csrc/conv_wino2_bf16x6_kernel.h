@@ -76,7 +76,7 @@ static inline size_t wino2_stat_blocks(int B, int H, int W, int max_wg) {
     return (ns < (size_t)max_wg ? ns : (size_t)max_wg) * 4;
 }
 
-// OUT_MODE 0: pooled NHWC (BN + ReLU + max), 1: pooled in the GRU layout [b][tx][co * Hp + ty] (+ its bf16x3 planes through
+// OUT_MODE 0: pooled NHWC (BN + ReLU + max), 1: pooled in the GRU layout [b][tx][co * Hp + ty] (+ its f16x2 planes through
 // `stats`), 2: raw NHWC + channel statistics (float2 {sum, sum of squares} at stats[(workgroup * 4 + row wave) * COUT + co]), 3: raw NHWC
 // ---- LDS access behind the compiler's back (producer waves) ---------------------------------------------------------------
 // hipcc orders every LDS read / write it can see behind ALL outstanding LDS-DMA of the wave (s_waitcnt vmcnt(0): it cannot prove
@@ -102,7 +102,13 @@ __device__ long long w2_dbg_stamps[2][32];
 // Fourth structure: 12 waves per workgroup -- 4 producers (raw patches by LDS-DMA three chunks deep, B^T d B, bf16x3, V[step & 1])
 // and 8 consumers (wave (i, n): transform row i, channel slice n: 4 accumulators, weights of its 4 frequencies one chunk ahead),
 // one barrier per chunk; a task's row transform goes through the V buffer its last chunk just left (two extra barriers per task).
-template <int CIN, int COUT, int OUT_MODE, int DBG = 0, int PRIO = 3>
+// F16 (round 4): the contraction on the fp16 matrix cores with the two-way split (f16_split.h) instead of bf16x6 -- the producers
+// write TWO planes (Vh, Vl' = residual * 2^11) instead of three (a third fewer split instructions and LDS writes), the consumers
+// issue THREE products per frequency and 16-deep step instead of six (Vl' Uh, Vh Ul', Vh (Uh 2^11): one accumulator, 2^11 too large,
+// scaled back in the epilogue; weights from prep_conv_w_wino_f16x3: same layout, three fp16 planes).  The part runs at its power
+// cap: the matrix products ARE the energy.  Needs inputs inside fp16's range (activations: yes; gradients only under the loss
+// scale of the backward).  The V buffers keep their 48 KB stride (the row-transform exchange of the epilogue needs it).
+template <int CIN, int COUT, int OUT_MODE, int DBG = 0, int PRIO = 3, bool F16 = false>
 __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpb, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, Wino2Geo geo, float2* __restrict__ stats, const float* __restrict__ zeros) {
@@ -237,13 +243,21 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                         const w2_f32x4 V[4] = {R[0] - R[2], R[1] + R[2], R[2] - R[1], R[1] - R[3]};
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            uint2 sh, sm, sl;
-                            split3_pair(V[j].x, V[j].y, sh.x, sm.x, sl.x);
-                            split3_pair(V[j].z, V[j].w, sh.y, sm.y, sl.y);
                             const unsigned d = vd + (4 * il + j) * 1024;
-                            w2_write64<0>(d, sh);
-                            w2_write64<W2_PLB>(d, sm);
-                            w2_write64<2 * W2_PLB>(d, sl);
+                            if constexpr (F16) {
+                                uint2 sh, sl;
+                                split2h_pair(V[j].x, V[j].y, sh.x, sl.x);
+                                split2h_pair(V[j].z, V[j].w, sh.y, sl.y);
+                                w2_write64<0>(d, sh);
+                                w2_write64<W2_PLB>(d, sl);
+                            } else {
+                                uint2 sh, sm, sl;
+                                split3_pair(V[j].x, V[j].y, sh.x, sm.x, sl.x);
+                                split3_pair(V[j].z, V[j].w, sh.y, sm.y, sl.y);
+                                w2_write64<0>(d, sh);
+                                w2_write64<W2_PLB>(d, sm);
+                                w2_write64<2 * W2_PLB>(d, sl);
+                            }
                         }
                     }
                 };
@@ -317,26 +331,37 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
             // step starts with an L2 round trip
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {
-                bf16x8 a[2][3], bq[2][3];
+                constexpr int NPA = F16 ? 2 : 3;
+                bf16x8 a[2][NPA], bq[2][3];
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
+                for (int jj = 0; jj < 2; ++jj) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
+                    for (int p = 0; p < NPA; ++p)
                         a[jj][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(abase + p * W2_PLB + (2 * jp + jj) * 1024));
-                        bq[jj][p] = __builtin_bit_cast(bf16x8, wq[2 * jp + jj][p]);
-                    }
-                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
-                if (!(DBG & 8)) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bq[jj][p] = __builtin_bit_cast(bf16x8, wq[2 * jp + jj][p]);
+                }
+                if (DBG & 8) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+                        acc[2 * jp + jj][0] += __builtin_bit_cast(float4, a[jj][0]).x + __builtin_bit_cast(float4, a[jj][1]).y + __builtin_bit_cast(float4, a[jj][NPA - 1]).z +
+                                               __builtin_bit_cast(float4, bq[jj][0]).x + __builtin_bit_cast(float4, bq[jj][1]).y + __builtin_bit_cast(float4, bq[jj][2]).z;
+                } else if constexpr (F16) {
+                    // a: 0 = Vh, 1 = Vl'; bq: 0 = Uh, 1 = Uh 2^11, 2 = Ul' -- the two cross terms first, then the main one
+                    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 2, 1};
+#pragma unroll
+                    for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj)
+                            acc[2 * jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[jj][HA[t3]]),
+                                                                                      __builtin_bit_cast(f16x8, bq[jj][HB[t3]]), acc[2 * jp + jj], 0, 0, 0);
+                } else {
+                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
 #pragma unroll
                     for (int t6 = 0; t6 < 6; ++t6)
 #pragma unroll
                         for (int jj = 0; jj < 2; ++jj)
                             acc[2 * jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[jj][PA[t6]], bq[jj][PB[t6]], acc[2 * jp + jj], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-                        acc[2 * jp + jj][0] += __builtin_bit_cast(float4, a[jj][0]).x + __builtin_bit_cast(float4, a[jj][1]).y + __builtin_bit_cast(float4, a[jj][2]).z +
-                                               __builtin_bit_cast(float4, bq[jj][0]).x + __builtin_bit_cast(float4, bq[jj][1]).y + __builtin_bit_cast(float4, bq[jj][2]).z;
                 }
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) if (!(DBG & 64)) load_w(gnxt + 2 * jp + jj, task_end ? chn : ch, wq[2 * jp + jj]);
@@ -394,7 +419,8 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                 const int co = ch * 64 + mn * 32 + m;
                 float ssum = 0.0f, ssq = 0.0f;
                 float sc_ = 1.0f, sh_ = 0.0f;
-                if (OUT_MODE <= 1) { sc_ = scale[co]; sh_ = shift[co]; }
+                constexpr float DESC = F16 ? H3_LO_INV : 1.0f;         // the f16x3 accumulators are 2^11 too large (exact power of two)
+                if (OUT_MODE <= 1) { sc_ = scale[co] * DESC; sh_ = shift[co]; }
                 {
                     const int gc = g0 + mi;
                     const int img = gc / TW, tx = gc - img * TW;
@@ -419,14 +445,13 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                                 const size_t oidx = ((size_t)img * geo.Wp + tx) * (COUT * geo.Hp) + (size_t)co * geo.Hp + ty0 + 4 * h;
                                 const float4 v4 = make_float4(pooled[0], pooled[1], pooled[2], pooled[3]);
                                 *reinterpret_cast<float4*>(out + oidx) = v4;
-                                if (stats) {           // bf16x3 planes [3][B * Wp][COUT * Hp] of the following GEMM's A operand
+                                if (stats) {           // f16x2 planes [2][B * Wp][COUT * Hp] (f16_split.h) of the following GEMM's A operand
                                     unsigned short* planes = reinterpret_cast<unsigned short*>(stats);
                                     const size_t plane = (size_t)geo.B * geo.Wp * (COUT * geo.Hp);
-                                    uint2 hh, mm, ll;
-                                    split3_quad(v4, hh, mm, ll);
+                                    uint2 hh, ll;
+                                    split2h_quad(v4, hh, ll);
                                     *reinterpret_cast<uint2*>(planes + oidx) = hh;
-                                    *reinterpret_cast<uint2*>(planes + plane + oidx) = mm;
-                                    *reinterpret_cast<uint2*>(planes + 2 * plane + oidx) = ll;
+                                    *reinterpret_cast<uint2*>(planes + plane + oidx) = ll;
                                 }
                             }
                         }
@@ -439,7 +464,7 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                                 for (int b = 0; b < 2; ++b) {
                                     const int gy = 2 * (ty0 + 4 * h + e) + a, gx = 2 * tx + b;
                                     if (tvalid && gx < W) {
-                                        const float v = Y[a][b][e];
+                                        const float v = Y[a][b][e] * DESC;
                                         out[(((size_t)img * H + gy) * W + gx) * COUT + co] = v;
                                         ssum += v;
                                         ssq = fmaf(v, v, ssq);
@@ -473,17 +498,17 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
 }
 
 // `attr_done`: the caller's per-device latch of the dynamic-LDS opt-in of THIS instantiation (sir_handle::attr_wino2[...])
-template <int CIN, int COUT, int OUT_MODE, int DBG = 0, int PRIO = 3>
+template <int CIN, int COUT, int OUT_MODE, int DBG = 0, int PRIO = 3, bool F16 = false>
 static inline hipError_t launch_conv_wino2(hipStream_t st, bool* attr_done, const float* x, const unsigned short* wpb, const float* scale,
                                            const float* shift, float* out, int B, int H, int W, float2* stats, const float* zeros, int max_wg = 256) {
     Wino2Geo g;
     if (!wino2_geo(B, H, W, CIN > COUT ? CIN : COUT, &g)) return hipErrorInvalidValue;
     if (!*attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino2_bf16x6_kernel<CIN, COUT, OUT_MODE, DBG, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino2_bf16x6_kernel<CIN, COUT, OUT_MODE, DBG, PRIO, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS_BYTES);
         if (e != hipSuccess) return e;
         *attr_done = true;
     }
     const int nwg = g.NS < max_wg ? g.NS : max_wg;
-    hipLaunchKernelGGL((conv3x3_wino2_bf16x6_kernel<CIN, COUT, OUT_MODE, DBG, PRIO>), dim3(nwg), dim3(W2_THREADS), W2_LDS_BYTES, st, x, wpb, scale, shift, out, g, stats, zeros);
+    hipLaunchKernelGGL((conv3x3_wino2_bf16x6_kernel<CIN, COUT, OUT_MODE, DBG, PRIO, F16>), dim3(nwg), dim3(W2_THREADS), W2_LDS_BYTES, st, x, wpb, scale, shift, out, g, stats, zeros);
     return hipGetLastError();
 }

@@ -84,6 +84,70 @@ static __global__ void prep_conv_wT_wino_bf16x3_kernel(const float* __restrict__
     prep_conv_wT_wino_bf16x3_elem(w, wpb, cin_f, cout_f, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+// ---- f16x3 form of the same weights (second-generation kernel with F16 = true; f16_split.h) ------------------------------------
+// Three fp16 planes per value, same layout: plane 0 = Uh = fp16(U), plane 1 = Uh * 2^11, plane 2 = Ul' = fp16((U - Uh) * 2^11).
+// With the activations split into (Vh, Vl') the kernel accumulates Vl' Uh + Vh Ul' + Vh (Uh 2^11) = 2^11 V U into ONE accumulator
+// (three MFMAs, no second accumulator: the consumers' registers are full) and the epilogue scales by 2^-11.  Uh * 2^11 is exact
+// for |U| < 32; larger transformed weights are clamped and flagged in the handle's status word (bit 3: SIR_EINVAL at the next
+// sir_check_status) -- conv weights of this model are O(0.1).
+__device__ __forceinline__ void split_w_f16x3(float u, unsigned short& p0, unsigned short& p1, unsigned short& p2, unsigned int* status) {
+    constexpr float LIM = 31.984375f;                       // 65504 / 2048
+    if (status && !(fabsf(u) <= LIM)) __hip_atomic_fetch_or(status, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u = __builtin_fminf(__builtin_fmaxf(u, -LIM), LIM);
+    const _Float16 hi = (_Float16)u;
+    const _Float16 hi2 = (_Float16)((float)hi * H3_LO_SCALE);
+    const _Float16 lo = (_Float16)((u - (float)hi) * H3_LO_SCALE);
+    p0 = __builtin_bit_cast(unsigned short, hi);
+    p1 = __builtin_bit_cast(unsigned short, hi2);
+    p2 = __builtin_bit_cast(unsigned short, lo);
+}
+__device__ __forceinline__ void prep_conv_w_wino_f16x3_elem(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin, int cout, int idx,
+                                                            unsigned int* status) {
+    const int total = cin * 16 * cout;
+    if (idx >= total) return;
+    const int e = idx & 15, co = (idx >> 4) % cout, g = (idx >> 4) / cout;
+    const int ci = (g / 16) * 16 + e, f = g % 16, i = f >> 2, j = f & 3;
+    const float* gk = w + ((size_t)co * cin + ci) * 9;
+    const float Gm[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+    float u = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float t = 0.0f;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) t = fmaf(gk[k * 3 + l], Gm[j][l], t);
+        u = fmaf(Gm[i][k], t, u);
+    }
+    if (j == 3) u = -u;
+    split_w_f16x3(u, wpb[idx], wpb[(size_t)total + idx], wpb[2 * (size_t)total + idx], status);
+}
+static __global__ void prep_conv_w_wino_f16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin, int cout,
+                                                     unsigned int* status) {
+    prep_conv_w_wino_f16x3_elem(w, wpb, cin, cout, blockIdx.x * blockDim.x + threadIdx.x, status);
+}
+__device__ __forceinline__ void prep_conv_wT_wino_f16x3_elem(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin_f, int cout_f,
+                                                             int idx, unsigned int* status) {
+    const int total = cout_f * 16 * cin_f;
+    if (idx >= total) return;
+    const int e = idx & 15, cop = (idx >> 4) % cin_f, g = (idx >> 4) / cin_f;
+    const int co_f = (g / 16) * 16 + e, f = g % 16, i = f >> 2, j = f & 3;
+    const float* gk = w + ((size_t)co_f * cin_f + cop) * 9;
+    const float Gm[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+    float u = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float t = 0.0f;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) t = fmaf(gk[8 - (k * 3 + l)], Gm[j][l], t);
+        u = fmaf(Gm[i][k], t, u);
+    }
+    if (j == 3) u = -u;
+    split_w_f16x3(u, wpb[idx], wpb[(size_t)total + idx], wpb[2 * (size_t)total + idx], status);
+}
+static __global__ void prep_conv_wT_wino_f16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin_f, int cout_f,
+                                                       unsigned int* status) {
+    prep_conv_wT_wino_f16x3_elem(w, wpb, cin_f, cout_f, blockIdx.x * blockDim.x + threadIdx.x, status);
+}
+
 // grid (ceil(ceil(W / 2) / 2), ceil(H / 32), B): one block of 16 x 2 tiles per workgroup
 // KNOCK (devtools/kernel_ab/bench_conv.hip timing experiments, results invalid; 0 in the product): bit 0 = no patch loads, bit 1 = no
 // transform / split / LDS writes, bit 2 = no MFMAs, bit 3 = no output stores, bit 4 = weight fragments loaded once per workgroup

@@ -16,51 +16,7 @@
 // Range: fp16's, |x| < 65504 (the GRU inputs are BatchNorm + ReLU outputs and GRU states; weights are O(0.1)); values
 // below 2^-14 keep an ABSOLUTE error of 2^-36.
 #pragma once
-#include "bf16x6_kernels.h"
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 sir_f16x2 __attribute__((ext_vector_type(2)));
-
-constexpr float H3_LO_SCALE = 2048.0f;                      // 2^11
-constexpr float H3_LO_INV = 1.0f / 2048.0f;
-
-// two floats -> packed hi halves, packed scaled-residual halves (a in the low 16 bits)
-__device__ __forceinline__ void split2h_pair(float a, float b, unsigned& h, unsigned& l) {
-    sir_f32x2 v = {a, b};
-    const sir_f16x2 hi = __builtin_convertvector(v, sir_f16x2);
-    v -= __builtin_convertvector(hi, sir_f32x2);            // exact
-    v *= H3_LO_SCALE;
-    const sir_f16x2 lo = __builtin_convertvector(v, sir_f16x2);
-    h = __builtin_bit_cast(unsigned, hi);
-    l = __builtin_bit_cast(unsigned, lo);
-}
-__device__ __forceinline__ void split2h_quad(const float4& v, uint2& h, uint2& l) {
-    split2h_pair(v.x, v.y, h.x, l.x);
-    split2h_pair(v.z, v.w, h.y, l.y);
-}
-
-// in [rows][K] fp32 (row stride ld_in) -> planes [2][rows][K] fp16; one thread = 8 consecutive k
-__device__ __forceinline__ void split2h_rows(const float* __restrict__ in, int ld_in, unsigned short* __restrict__ out, size_t rows, int K,
-                                             size_t gidx, size_t nthreads) {
-    const int k8n = K / 8;
-    const size_t total = rows * k8n, plane = rows * (size_t)K;
-    for (size_t idx = gidx; idx < total; idx += nthreads) {
-        const size_t row = idx / k8n;
-        const int k8 = idx % k8n;
-        const float4 v0 = *reinterpret_cast<const float4*>(in + row * ld_in + k8 * 8);
-        const float4 v1 = *reinterpret_cast<const float4*>(in + row * ld_in + k8 * 8 + 4);
-        uint2 h0, l0, h1, l1;
-        split2h_quad(v0, h0, l0);
-        split2h_quad(v1, h1, l1);
-        const size_t o = row * K + (size_t)k8 * 8;
-        *reinterpret_cast<uint4*>(out + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-        *reinterpret_cast<uint4*>(out + plane + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
-    }
-}
-static __global__ __launch_bounds__(256) void split2h_kernel(const float* __restrict__ in, int ld_in, unsigned short* __restrict__ out,
-                                                              size_t rows, int K) {
-    split2h_rows(in, ld_in, out, rows, K, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
-}
+#include "bf16x6_kernels.h"     // (includes f16_split.h: the two-way split itself)
 
 // ------------------------------------------------------------------------------------------
 // C[m][z*N + n] = sum_k A[m][k] * Bz[n][k] + biasz[n] with A, B given as f16x2 planes (same contract as
@@ -241,4 +197,19 @@ static __global__ __launch_bounds__(512) void gemm_nt_f16x3_kernel(
 
 static inline bool gemm_f16x3_ok(int M, int N, int K) {
     return N % H3_BN == 0 && K % H3_BK == 0 && (size_t)2 * M * K < ((size_t)1 << 31) && (size_t)2 * N * K < ((size_t)1 << 31);
+}
+
+// C[M][2 N] (+ bias) = A x [B0; B1]^T from pre-split f16x2 planes (the GRU input projections: N = 768 per direction)
+static inline hipError_t launch_gemm_nt_f16x3(sir_handle* h, hipStream_t st, const unsigned short* Ap, const unsigned short* Bp0,
+                                              const unsigned short* Bp1, const float* bias0, const float* bias1, float* C, int ldc,
+                                              int M, int N, int K) {
+    if (!gemm_f16x3_ok(M, N, K)) return hipErrorInvalidValue;
+    if (!h->attr_gemm_v3) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_f16x3_kernel<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, h3_lds_bytes(3));
+        if (e != hipSuccess) return e;
+        h->attr_gemm_v3 = true;
+    }
+    const int nwg = ((M + H3_BM - 1) / H3_BM) * 2 * (N / H3_BN);
+    hipLaunchKernelGGL((gemm_nt_f16x3_kernel<3, 0>), dim3(nwg), dim3(512), h3_lds_bytes(3), st, Ap, Bp0, Bp1, bias0, bias1, C, ldc, M, N, K);
+    return hipGetLastError();
 }

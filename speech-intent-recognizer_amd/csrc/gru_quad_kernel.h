@@ -74,7 +74,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     float* __restrict__ gates, unsigned long long* xbuf, unsigned int* status, int dbg, unsigned epoch, unsigned short* __restrict__ yplanes,
     const uint4* __restrict__ wfrag0, const uint4* __restrict__ wfrag1) {
     // wfrag0/1 (optional): prep_whh_quad_kernel output for direction 0 / 1
-    // yplanes (optional): bf16x3 planes [3][B * S][512] of y, the A operand of the next layer's input projection
+    // yplanes (optional): f16x2 planes [2][B * S][512] (f16_split.h) of y, the A operand of the next layer's input projection
     // dbg (timing experiments only, results invalid): bit 0 = do not wait for the granules, bit 1 = skip the MFMAs,
     // bit 2 = skip publish + receive; fault injection for the status-word test: bit 3 = quarter 3 never publishes (its
     // peers time out), bit 4 = spin limit 4096 instead of 2^22 (so that the injected timeout takes milliseconds);
@@ -298,9 +298,10 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
             *reinterpret_cast<float4*>(y + yidx) = hprev;
             if (yplanes) {
                 const size_t plane = (size_t)B * S * 512;
-                *reinterpret_cast<uint2*>(yplanes + yidx) = ph;
-                *reinterpret_cast<uint2*>(yplanes + plane + yidx) = pm;
-                *reinterpret_cast<uint2*>(yplanes + 2 * plane + yidx) = pl;
+                uint2 yh, yl;
+                split2h_quad(hprev, yh, yl);
+                *reinterpret_cast<uint2*>(yplanes + yidx) = yh;
+                *reinterpret_cast<uint2*>(yplanes + plane + yidx) = yl;
             }
             if (SAVE) {
                 float* gsv = gates + (((size_t)b * S + t) * 2 + dir) * 1024 + u0;

@@ -1,6 +1,7 @@
 // sir_model_infer: eval-mode CNNAudioGRU.forward + argmax (models/models.py:41-68, scripts/evaluate.py:82-83)
 // as a fixed sequence of hand-written kernels on one stream.  See model_kernels.h for the kernels.
 #include "bf16x6_kernels.h"
+#include "f16x3_kernels.h"
 #include "conv_wino_bf16x6_kernel.h"
 #include "conv_wino2_bf16x6_kernel.h"
 
@@ -18,8 +19,8 @@ enum WsBuf {
     WS_WP3,      // (unused)
     WS_BN,       // folded BN: scale[224] then shift[224] (channels of bn1|bn2|bn3)
     WS_WHT,      // W_hh fragments of the recurrence kernel, [4 (layer, direction)][768 * 256 * 6 bytes]
-    WS_XS,       // bf16x3 planes of the current GEMM A operand, [3][B*S][1024] bf16
-    WS_WS,       // bf16x3 planes of W_ih: l0 [2][3][768][1024], l1 [2][3][768][512]
+    WS_XS,       // f16x2 planes (f16_split.h) of the current GEMM A operand, [2][B*S][1024] fp16
+    WS_WS,       // f16x2 planes of W_ih: l0 [2 directions][2][768][1024], l1 [2][2][768][512]
     WS_WCB,      // bf16x3 planes of the conv2 / conv3 weights
     WS_GXB,      // (unused: the exchange granules of the GRU clusters live in handle-owned buffers, sir_xbuf_acquire)
     WS_GFL,      // (unused)
@@ -49,8 +50,8 @@ void ws_sizes(const Dims& d, size_t* bytes) {
     bytes[WS_WP3] = 0;
     bytes[WS_BN] = (size_t)2 * 224 * 4;
     bytes[WS_WHT] = (size_t)4 * 768 * 256 * 6;                  // W_hh as the resident bf16x3 MFMA fragments of the recurrence kernel
-    bytes[WS_XS] = B * d.S * 1024 * 3 * 2;
-    bytes[WS_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512) * 2;
+    bytes[WS_XS] = B * d.S * 1024 * 2 * 2;
+    bytes[WS_WS] = ((size_t)2 * 2 * 768 * 1024 + (size_t)2 * 2 * 768 * 512) * 2;
     bytes[WS_WCB] = ((size_t)3 * 32 * 16 * 64 + (size_t)3 * 64 * 16 * 128 + (size_t)3 * 64 * 9 * 128) * 2;   // conv2, conv3: 16 Winograd frequencies per (cout, cin); conv3 again with 9 taps for the direct kernel (shapes the Winograd kernel does not cover)
     bytes[WS_GXB] = 0;
     bytes[WS_GFL] = 0;
@@ -118,11 +119,18 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     float* wht = (float*)(ws + off[WS_WHT]);
     unsigned short* xs = (unsigned short*)(ws + off[WS_XS]);
     unsigned short* wsl0 = (unsigned short*)(ws + off[WS_WS]);
-    unsigned short* wsl1 = wsl0 + (size_t)2 * 3 * 768 * 1024;
+    unsigned short* wsl1 = wsl0 + (size_t)2 * 2 * 768 * 1024;
     unsigned short* wcb2 = (unsigned short*)(ws + off[WS_WCB]);
     unsigned short* wcb3 = wcb2 + (size_t)3 * 32 * 16 * 64;       // Winograd form
     unsigned short* wcb3d = wcb3 + (size_t)3 * 64 * 16 * 128;     // direct form (fallback)
     const int B = d.B, S = d.S;
+
+    // conv2 / conv3 as Winograd F(2x2, 3x3) -- the 2x2 output tile is the pooling window -- on the producer / consumer kernel
+    // (conv_wino2_bf16x6_kernel.h); shapes it does not cover (batch x map beyond 32-bit offsets) keep the first-generation kernels
+    Wino2Geo geo2, geo3;
+    const bool w2ok = wino2_geo(B, 32, d.wp1, 64, &geo2) && wino2_geo(B, 16, d.wp2, 128, &geo3);
+    const bool w2c2 = w2ok && (sir_wino2_mask() & 1), w2c3 = w2ok && (sir_wino2_mask() & 2);
+    const bool f16c2 = w2c2 && (sir_f16_mask() & 1), f16c3 = w2c3 && (sir_f16_mask() & 2);
 
     // ---- weight preparation -------------------------------------------------------------
     // skipped when the caller vouches (sir_model_set_weights_version) that the weights are the ones prepared
@@ -139,12 +147,16 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
             hipLaunchKernelGGL(prep_bn_kernel, dim3(1), dim3(128), 0, st, w->bn_w[i], w->bn_b[i], w->bn_mean[i], w->bn_var[i],
                                bns + bn_o[i], bnt + bn_o[i], bn_c[i]);
         for (int i = 0; i < 4; ++i) sir_prep_whh_quad(st, w->gru_w_hh[i], (unsigned char*)wht + (size_t)i * 768 * 256 * 6);
-        hipLaunchKernelGGL(prep_conv_w_wino_bf16x3_kernel, dim3((32 * 16 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], wcb2, 32, 64);
-        hipLaunchKernelGGL(prep_conv_w_wino_bf16x3_kernel, dim3((64 * 16 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], wcb3, 64, 128);
+        // (the weight planes are prepared in the arithmetic of the kernel that will read them: f16x3 for the second-generation
+        // Winograd kernel's forward stages, bf16x3 for the first-generation / direct fallbacks)
+        if (f16c2) hipLaunchKernelGGL(prep_conv_w_wino_f16x3_kernel, dim3((32 * 16 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], wcb2, 32, 64, h->status);
+        else hipLaunchKernelGGL(prep_conv_w_wino_bf16x3_kernel, dim3((32 * 16 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], wcb2, 32, 64);
+        if (f16c3) hipLaunchKernelGGL(prep_conv_w_wino_f16x3_kernel, dim3((64 * 16 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], wcb3, 64, 128, h->status);
+        else hipLaunchKernelGGL(prep_conv_w_wino_bf16x3_kernel, dim3((64 * 16 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], wcb3, 64, 128);
         hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, dim3((64 * 9 * 128 + 255) / 256), dim3(256), 0, st, w->conv_w[2], wcb3d, 64, 128);
         for (int dir = 0; dir < 2; ++dir) {
-            hipLaunchKernelGGL(split3_kernel, dim3(384), dim3(256), 0, st, w->gru_w_ih[dir], 1024, wsl0 + (size_t)dir * 3 * 768 * 1024, (size_t)768, 1024);
-            hipLaunchKernelGGL(split3_kernel, dim3(192), dim3(256), 0, st, w->gru_w_ih[2 + dir], 512, wsl1 + (size_t)dir * 3 * 768 * 512, (size_t)768, 512);
+            hipLaunchKernelGGL(split2h_kernel, dim3(384), dim3(256), 0, st, w->gru_w_ih[dir], 1024, wsl0 + (size_t)dir * 2 * 768 * 1024, (size_t)768, 1024);
+            hipLaunchKernelGGL(split2h_kernel, dim3(192), dim3(256), 0, st, w->gru_w_ih[2 + dir], 512, wsl1 + (size_t)dir * 2 * 768 * 512, (size_t)768, 512);
         }
         if (!pe) { pe = &h->prep[h->prep_next]; h->prep_next = (h->prep_next + 1) % 4; }
         pe->ws = workspace; pe->version = h->weights_version; pe->key = prep_key;
@@ -157,13 +169,12 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
         hipLaunchKernelGGL(conv1_mfma_bn_relu_pool_kernel, dim3((d.wp1 + C1_PCOLS - 1) / C1_PCOLS, 1, B), dim3(256), 0, st, feats,
                            w->conv_w[0], bns, bnt, a1, 64, d.T, 32, d.wp1);
     }
-    // conv2 / conv3 as Winograd F(2x2, 3x3) -- the 2x2 output tile is the pooling window -- on the producer / consumer kernel
-    // (conv_wino2_bf16x6_kernel.h); shapes it does not cover (batch x map beyond 32-bit offsets) keep the first-generation kernels
-    Wino2Geo geo2, geo3;
-    const bool w2ok = wino2_geo(B, 32, d.wp1, 64, &geo2) && wino2_geo(B, 16, d.wp2, 128, &geo3);
     {
         SirProfScope prof(h, SIR_K_CONV2, st);
-        if (w2ok && (sir_wino2_mask() & 1))
+        if (f16c2)
+            SIR_HIP_TRY((launch_conv_wino2<32, 64, 0, 0, 3, true>(st, &h->attr_wino2[5], a1, (const unsigned short*)wcb2, bns + 32, bnt + 32, a2, B, 32, d.wp1,
+                                                                (float2*)nullptr, h->zero_page, h->num_cus)));
+        else if (w2c2)
             SIR_HIP_TRY((launch_conv_wino2<32, 64, 0>(st, &h->attr_wino2[0], a1, (const unsigned short*)wcb2, bns + 32, bnt + 32, a2, B, 32, d.wp1,
                                                     (float2*)nullptr, h->zero_page, h->num_cus)));
         else
@@ -171,10 +182,13 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
                                a1, (const unsigned short*)wcb2, bns + 32, bnt + 32, a2, 32, d.wp1, 16, d.wp2, (float2*)nullptr);
     }
     {
-        // conv3 stores straight into the GRU input layout [B][S][c*8+h] (models.py:55-57) and writes the bf16x3 planes of
+        // conv3 stores straight into the GRU input layout [B][S][c*8+h] (models.py:55-57) and writes the f16x2 planes of
         // the first input projection's A operand beside it
         SirProfScope prof(h, SIR_K_CONV3, st);
-        if (w2ok && (sir_wino2_mask() & 2))
+        if (f16c3)
+            SIR_HIP_TRY((launch_conv_wino2<64, 128, 1, 0, 3, true>(st, &h->attr_wino2[6], a2, (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, B, 16, d.wp2,
+                                                                 (float2*)xs, h->zero_page, h->num_cus)));
+        else if (w2c3)
             SIR_HIP_TRY((launch_conv_wino2<64, 128, 1>(st, &h->attr_wino2[1], a2, (const unsigned short*)wcb3, bns + 96, bnt + 96, x0, B, 16, d.wp2,
                                                      (float2*)xs, h->zero_page, h->num_cus)));
         else
@@ -187,13 +201,13 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     const int M = B * S;
     {
         SirProfScope prof(h, SIR_K_GEMM_IH0, st);
-        SIR_HIP_TRY(launch_gemm_nt_bf16x6(h, st, (const unsigned short*)xs, (const unsigned short*)wsl0,
-                                          (const unsigned short*)(wsl0 + (size_t)3 * 768 * 1024), w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024));
+        SIR_HIP_TRY(launch_gemm_nt_f16x3(h, st, (const unsigned short*)xs, (const unsigned short*)wsl0,
+                                         (const unsigned short*)(wsl0 + (size_t)2 * 768 * 1024), w->gru_b_ih[0], w->gru_b_ih[1], gi, 1536, M, 768, 1024));
     }
     {
         SirProfScope prof(h, SIR_K_GRU0, st);
         if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
-        // layer 0 also writes the bf16x3 planes of ITS output: the A operand of the layer-1 projection
+        // layer 0 also writes the f16x2 planes of ITS output: the A operand of the layer-1 projection
         const int rc = sir_launch_gru_quad(h, st, false, gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S, nullptr,
                                            xs, wht, (unsigned char*)wht + (size_t)768 * 256 * 6);
         if (rc != SIR_OK) return rc;
@@ -201,8 +215,8 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
     }
     {
         SirProfScope prof(h, SIR_K_GEMM_IH1, st);
-        SIR_HIP_TRY(launch_gemm_nt_bf16x6(h, st, (const unsigned short*)xs, (const unsigned short*)wsl1,
-                                          (const unsigned short*)(wsl1 + (size_t)3 * 768 * 512), w->gru_b_ih[2], w->gru_b_ih[3], gi, 1536, M, 768, 512));
+        SIR_HIP_TRY(launch_gemm_nt_f16x3(h, st, (const unsigned short*)xs, (const unsigned short*)wsl1,
+                                         (const unsigned short*)(wsl1 + (size_t)2 * 768 * 512), w->gru_b_ih[2], w->gru_b_ih[3], gi, 1536, M, 768, 512));
     }
     {
         SirProfScope prof(h, SIR_K_GRU1, st);

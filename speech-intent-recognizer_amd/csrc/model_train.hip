@@ -3,6 +3,7 @@
 // (sir_model_train_bwd) and multi-tensor Adam (sir_adam_step).  Replaces the body of
 // train_epoch (scripts/train.py:90-107: forward, criterion, loss.backward(), optimizer.step()).
 #include "bf16x6_kernels.h"
+#include "f16x3_kernels.h"
 #include "train_kernels.h"
 #include "conv_wino2_bf16x6_kernel.h"
 #include "wgrad_bf16x6_kernel.h"
@@ -21,8 +22,8 @@ enum TrainBuf {
     TB_DY1, TB_DY0, TB_DGI, TB_DGH, TB_DX0, TB_DZ3, TB_DA2, TB_DZ2, TB_DA1,
     TB_SMALL,     // daw_part [B][512], dab_part [B], conv1 wgrad partials
     TB_SLAB,      // split-K / wgrad partial slabs
-    TB_XS,        // bf16x3 planes of the forward GEMM A operand [3][B*S][1024]
-    TB_WS,        // bf16x3 planes of W_ih (l0 [2][3][768][1024], l1 [2][3][768][512])
+    TB_XS,        // f16x2 planes (f16_split.h) of the forward GEMM A operand [2][B*S][1024]
+    TB_WS,        // f16x2 planes of W_ih (l0 [2 directions][2][768][1024], l1 [2][2][768][512])
     TB_WCB,       // bf16x3 conv weights: conv2, conv3 forward, then conv2, conv3 data-gradient forms
     TB_GXB,       // (unused: exchange granules live in handle-owned buffers, sir_xbuf_acquire)
     TB_GFL,       // paired GRU status word
@@ -128,8 +129,8 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     }
     if ((size_t)64 * 16 * 128 * 64 > slab) slab = (size_t)64 * 16 * 128 * 64;      // Winograd weight-gradient slabs: 64 strips of conv3, 128 of conv2
     n[TB_SLAB] = slab + (size_t)WGR_PARTS * 16 * 128 * 64;      // + the partial sums of the two-pass wgrad reduce
-    n[TB_XS] = (B * S * 1024 * 3 + 1) / 2;                       // ushort count / 2 (sizes are in floats)
-    n[TB_WS] = ((size_t)2 * 3 * 768 * 1024 + (size_t)2 * 3 * 768 * 512 + 1) / 2;
+    n[TB_XS] = (B * S * 1024 * 2 + 1) / 2;                       // ushort count / 2 (sizes are in floats)
+    n[TB_WS] = ((size_t)2 * 2 * 768 * 1024 + (size_t)2 * 2 * 768 * 512 + 1) / 2;
     // conv2 forward and the conv3 data gradient in Winograd form (16 frequencies), conv3 forward and the conv2 data gradient direct (9 taps)
     n[TB_WCB] = ((size_t)(3 * 32 * 16 * 64 + 3 * 32 * 9 * 64) + (size_t)3 * 64 * 16 * 128 + (size_t)3 * 128 * 16 * 64 + (size_t)3 * 64 * 9 * 128 + 1) / 2;
     n[TB_GXB] = 64;
@@ -177,7 +178,7 @@ TPtrs carve(void* ws, const size_t* off) {
     p.da2 = (float*)(b + off[TB_DA2]); p.dz2 = (float*)(b + off[TB_DZ2]); p.da1 = (float*)(b + off[TB_DA1]);
     p.small = (float*)(b + off[TB_SMALL]); p.slab = (float*)(b + off[TB_SLAB]);
     p.xs = (unsigned short*)(b + off[TB_XS]);
-    p.wsl0 = (unsigned short*)(b + off[TB_WS]); p.wsl1 = p.wsl0 + (size_t)2 * 3 * 768 * 1024;
+    p.wsl0 = (unsigned short*)(b + off[TB_WS]); p.wsl1 = p.wsl0 + (size_t)2 * 2 * 768 * 1024;
     p.wcb2 = (unsigned short*)(b + off[TB_WCB]); p.wcb3 = p.wcb2 + (size_t)3 * 32 * 16 * 64;
     p.wcb2t = p.wcb3 + (size_t)3 * 64 * 16 * 128; p.wcb3t = p.wcb2t + (size_t)3 * 32 * 9 * 64;
     p.wcb3d = p.wcb3t + (size_t)3 * 128 * 16 * 64;           // conv3 forward with 9 taps: only for shapes the Winograd kernel does not cover
@@ -243,6 +244,7 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     Wino2Geo geo2, geo3;
     const bool w2ok_all = wino2_geo(B, 32, d.wp1, 64, &geo2) && wino2_geo(B, 16, d.wp2, 128, &geo3);
     const bool w2c2 = w2ok_all && (sir_wino2_mask() & 1), w2c3 = w2ok_all && (sir_wino2_mask() & 2);
+    const bool f16c2 = w2c2 && (sir_f16_mask() & 1), f16c3 = w2c3 && (sir_f16_mask() & 2);     // forward stages on the f16x3 arithmetic
     {   // all weight re-layouts of this step, the backward's included (the weights do not change before it runs)
         SirProfScope prof(h, SIR_K_T_PREP, st);
         PrepJobs pj{};
@@ -251,14 +253,15 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
             pj.kind[nj] = kind; pj.src[nj] = src; pj.dst[nj] = dst; pj.a[nj] = a; pj.b[nj] = b; pj.block0[nj] = blocks;
             blocks += nblk; ++nj;
         };
-        add(4, w->conv_w[1], p.wcb2, 32, 64, (32 * 16 * 64 + 255) / 256);       // conv2 forward: Winograd frequencies
-        add(4, w->conv_w[2], p.wcb3, 64, 128, (64 * 16 * 128 + 255) / 256);     // conv3 forward: Winograd frequencies
+        pj.status = h->status;
+        add(f16c2 ? 6 : 4, w->conv_w[1], p.wcb2, 32, 64, (32 * 16 * 64 + 255) / 256);       // conv2 forward: Winograd frequencies
+        add(f16c3 ? 6 : 4, w->conv_w[2], p.wcb3, 64, 128, (64 * 16 * 128 + 255) / 256);     // conv3 forward: Winograd frequencies
         if (!w2c3) add(1, w->conv_w[2], p.wcb3d, 64, 128, (64 * 9 * 128 + 255) / 256);
         add(2, w->conv_w[1], p.wcb2t, 32, 64, (32 * 9 * 64 + 255) / 256);
         add(5, w->conv_w[2], p.wcb3t, 64, 128, (128 * 16 * 64 + 255) / 256);   // conv3 data gradient: Winograd frequencies of the flipped taps
         for (int dir = 0; dir < 2; ++dir) {
-            add(0, w->gru_w_ih[dir], p.wsl0 + (size_t)dir * 3 * 768 * 1024, 1024, 768, 384);
-            add(0, w->gru_w_ih[2 + dir], p.wsl1 + (size_t)dir * 3 * 768 * 512, 512, 768, 192);
+            add(0, w->gru_w_ih[dir], p.wsl0 + (size_t)dir * 2 * 768 * 1024, 1024, 768, 384);
+            add(0, w->gru_w_ih[2 + dir], p.wsl1 + (size_t)dir * 2 * 768 * 512, 512, 768, 192);
         }
         pj.block0[nj] = blocks;
         pj.njobs = nj;
@@ -286,7 +289,10 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     // conv2 block: raw conv + partial statistics on MFMA, finalize, BN+ReLU+pool
     {
         { SirProfScope prof(h, SIR_K_T_CONV2, st);
-        if (w2c2)
+        if (f16c2)
+            SIR_HIP_TRY((launch_conv_wino2<32, 64, 2, 0, 3, true>(st, &h->attr_wino2[7], (const float*)p.a1, (const unsigned short*)p.wcb2, (const float*)nullptr,
+                                                                (const float*)nullptr, p.z2, B, 32, d.wp1, p.stats, h->zero_page, h->num_cus)));
+        else if (w2c2)
             SIR_HIP_TRY((launch_conv_wino2<32, 64, 2>(st, &h->attr_wino2[2], (const float*)p.a1, (const unsigned short*)p.wcb2, (const float*)nullptr,
                                                     (const float*)nullptr, p.z2, B, 32, d.wp1, p.stats, h->zero_page, h->num_cus)));
         else
@@ -302,7 +308,10 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     }
     {
         { SirProfScope prof(h, SIR_K_T_CONV3, st);
-        if (w2c3)
+        if (f16c3)
+            SIR_HIP_TRY((launch_conv_wino2<64, 128, 2, 0, 3, true>(st, &h->attr_wino2[8], (const float*)p.a2, (const unsigned short*)p.wcb3, (const float*)nullptr,
+                                                                 (const float*)nullptr, p.z3, B, 16, d.wp2, p.stats, h->zero_page, h->num_cus)));
+        else if (w2c3)
             SIR_HIP_TRY((launch_conv_wino2<64, 128, 2>(st, &h->attr_wino2[3], (const float*)p.a2, (const unsigned short*)p.wcb3, (const float*)nullptr,
                                                      (const float*)nullptr, p.z3, B, 16, d.wp2, p.stats, h->zero_page, h->num_cus)));
         else
@@ -320,9 +329,9 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
 
     const int M = B * S;
     { SirProfScope prof(h, SIR_K_T_GEMM_IH0, st);
-    hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, (const float*)p.x0, 1024, p.xs, (size_t)M, 1024);
-    SIR_HIP_TRY(launch_gemm_nt_bf16x6(h, st, (const unsigned short*)p.xs, (const unsigned short*)p.wsl0,
-                       (const unsigned short*)(p.wsl0 + (size_t)3 * 768 * 1024), w->gru_b_ih[0], w->gru_b_ih[1], p.gi, 1536, M, 768, 1024)); }
+    hipLaunchKernelGGL(split2h_kernel, dim3(2048), dim3(256), 0, st, (const float*)p.x0, 1024, p.xs, (size_t)M, 1024);
+    SIR_HIP_TRY(launch_gemm_nt_f16x3(h, st, (const unsigned short*)p.xs, (const unsigned short*)p.wsl0,
+                       (const unsigned short*)(p.wsl0 + (size_t)2 * 768 * 1024), w->gru_b_ih[0], w->gru_b_ih[1], p.gi, 1536, M, 768, 1024)); }
     { SirProfScope prof(h, SIR_K_T_GRU0, st);
     if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
     rc = sir_launch_gru_quad(h, st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0);
@@ -330,15 +339,15 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
     if (rc != SIR_OK) return rc;
     const float* y0in = p.y0;
     { SirProfScope prof(h, SIR_K_T_GEMM_IH1, st);
-    if (dropout_p > 0.0f) {                                   // dropout + the bf16x3 planes of its output in one pass
-        hipLaunchKernelGGL(dropout_split3_kernel, dim3(2048), dim3(256), 0, st, (const float*)p.y0, p.y0d, p.xs, (size_t)M * 512,
+    if (dropout_p > 0.0f) {                                   // dropout + the f16x2 planes of its output in one pass
+        hipLaunchKernelGGL(dropout_split2h_kernel, dim3(2048), dim3(256), 0, st, (const float*)p.y0, p.y0d, p.xs, (size_t)M * 512,
                            dropout_p, (unsigned long long)dropout_seed);
         y0in = p.y0d;
     } else {
-        hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, st, y0in, 512, p.xs, (size_t)M, 512);
+        hipLaunchKernelGGL(split2h_kernel, dim3(2048), dim3(256), 0, st, y0in, 512, p.xs, (size_t)M, 512);
     }
-    SIR_HIP_TRY(launch_gemm_nt_bf16x6(h, st, (const unsigned short*)p.xs, (const unsigned short*)p.wsl1,
-                       (const unsigned short*)(p.wsl1 + (size_t)3 * 768 * 512), w->gru_b_ih[2], w->gru_b_ih[3], p.gi, 1536, M, 768, 512)); }
+    SIR_HIP_TRY(launch_gemm_nt_f16x3(h, st, (const unsigned short*)p.xs, (const unsigned short*)p.wsl1,
+                       (const unsigned short*)(p.wsl1 + (size_t)2 * 768 * 512), w->gru_b_ih[2], w->gru_b_ih[3], p.gi, 1536, M, 768, 512)); }
     { SirProfScope prof(h, SIR_K_T_GRU1, st);
     if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
     rc = sir_launch_gru_quad(h, st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1);

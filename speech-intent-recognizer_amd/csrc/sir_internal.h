@@ -75,7 +75,7 @@ struct sir_handle {
     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) latches, per handle = per device (a process-wide static would skip
     // the second device of a process that drives several)
     bool attr_gemm_v3, attr_gru_quad, attr_gru_bwd, attr_tn, attr_wgrad;
-    bool attr_wino2[8];                // conv3x3_wino2_bf16x6_kernel instantiations (model_infer.hip / model_train.hip index them)
+    bool attr_wino2[16];               // conv3x3_wino2_bf16x6_kernel instantiations (model_infer.hip / model_train.hip index them)
     float* zero_page;                  // 4 KB of zeros: DMA source of the second-generation Winograd kernel's out-of-image pixels
     int num_cus;                       // persistent kernels launch one workgroup per CU
     // Exchange-granule buffers of the cluster kernels (GRU recurrences).  They are OWNED by the handle (hipMalloc), one per
@@ -170,6 +170,7 @@ static inline int sir_cluster_leave(sir_handle* h, hipStream_t st) {
 int sir_wino2_mask();
 int sir_wgw_mask();      // SIR_WGW: convolution weight gradients in Winograd form: bit 0 = conv2, bit 1 = conv3 (default 3)
 int sir_tn2_mask();      // SIR_TN2: GRU backward GEMMs on the producer / consumer kernel: bit 0 = dW, bit 1 = dX on 128-row tiles, bit 2 = dX on 64-row tiles, bit 3 = a dX that would take 64-row tiles runs as two K halves on 128-row tiles instead (default 15)
+int sir_f16_mask();      // SIR_F16: stages on the f16x3 arithmetic (f16_split.h) instead of bf16x6: bit 0 = conv2 forward, bit 1 = conv3 forward (inference and training) (default 3)
 int sir_bwd_streams();   // SIR_BWD_STREAMS: 1 = the backward's off-chain weight-gradient launches on a second, handle-owned stream (default 0)
 
 int sir_check_hip(hipError_t e, const char* what);

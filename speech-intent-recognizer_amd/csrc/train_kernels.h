@@ -220,11 +220,11 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, size_t idx
     return (float)(unsigned)(x >> 40) * (1.0f / 16777216.0f) >= p;
 }
 
-// out = dropout(in) AND the bf16x3 planes [3][n] of out (the A operand of the next layer's input projection) in one pass;
+// out = dropout(in) AND the f16x2 planes [2][n] of out (the A operand of the next layer's input projection) in one pass;
 // one thread = 8 consecutive elements (n is a multiple of 8: rows of 512)
-static __global__ __launch_bounds__(256) void dropout_split3_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                     unsigned short* __restrict__ planes, size_t n, float p,
-                                                                     unsigned long long seed) {
+static __global__ __launch_bounds__(256) void dropout_split2h_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                      unsigned short* __restrict__ planes, size_t n, float p,
+                                                                      unsigned long long seed) {
     const float sc = 1.0f / (1.0f - p);
     for (size_t i8 = (size_t)blockIdx.x * 256 + threadIdx.x; i8 < n / 8; i8 += (size_t)gridDim.x * 256) {
         const size_t i = i8 * 8;
@@ -236,12 +236,11 @@ static __global__ __launch_bounds__(256) void dropout_split3_kernel(const float*
         const float4 v0 = make_float4(v[0], v[1], v[2], v[3]), v1 = make_float4(v[4], v[5], v[6], v[7]);
         *reinterpret_cast<float4*>(out + i) = v0;
         *reinterpret_cast<float4*>(out + i + 4) = v1;
-        uint2 h0, m0, l0, h1, m1, l1;
-        split3_quad(v0, h0, m0, l0);
-        split3_quad(v1, h1, m1, l1);
+        uint2 h0, l0, h1, l1;
+        split2h_quad(v0, h0, l0);
+        split2h_quad(v1, h1, l1);
         *reinterpret_cast<uint4*>(planes + i) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-        *reinterpret_cast<uint4*>(planes + n + i) = make_uint4(m0.x, m0.y, m1.x, m1.y);
-        *reinterpret_cast<uint4*>(planes + 2 * n + i) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        *reinterpret_cast<uint4*>(planes + n + i) = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
 }
 
@@ -524,9 +523,10 @@ __device__ __forceinline__ void prep_whh_bwd_elem(const float* __restrict__ w, f
 }
 
 // Every per-step re-layout of the weights (they change with each optimizer step) in ONE launch: a dozen ~5 us launches
-// otherwise.  kind 0: split3_rows (a = ld_in = K, b = rows), 1: prep_conv_w_bf16x3 (a = cin, b = cout),
+// otherwise.  kind 0: split2h_rows (a = ld_in = K, b = rows), 1: prep_conv_w_bf16x3 (a = cin, b = cout),
 // 2: prep_conv_wT_bf16x3 (a = cin_f, b = cout_f), 3: prep_whh_bwd, 4: prep_conv_w_wino_bf16x3 (a = cin, b = cout),
-// 5: prep_conv_wT_wino_bf16x3 (a = cin_f, b = cout_f).  Job j owns blocks [block0[j], block0[j+1]).
+// 5: prep_conv_wT_wino_bf16x3 (a = cin_f, b = cout_f), 6 / 7: the f16x3 forms of 4 / 5 (conv_wino_bf16x6_kernel.h).  Job j owns
+// blocks [block0[j], block0[j+1]).
 constexpr int PREP_MAX_JOBS = 12;
 struct PrepJobs {
     const float* src[PREP_MAX_JOBS];
@@ -534,6 +534,7 @@ struct PrepJobs {
     int kind[PREP_MAX_JOBS], a[PREP_MAX_JOBS], b[PREP_MAX_JOBS];
     int block0[PREP_MAX_JOBS + 1];
     int njobs;
+    unsigned int* status;        // the handle's status word (kinds 6 / 7 flag weights outside the f16x3 range)
 };
 static __global__ __launch_bounds__(256) void train_prep_kernel(PrepJobs jobs) {
     int j = 0;
@@ -542,11 +543,13 @@ static __global__ __launch_bounds__(256) void train_prep_kernel(PrepJobs jobs) {
     const int idx = lb * 256 + threadIdx.x;
     const float* __restrict__ src = jobs.src[j];
     switch (jobs.kind[j]) {
-        case 0: split3_rows(src, jobs.a[j], (unsigned short*)jobs.dst[j], (size_t)jobs.b[j], jobs.a[j], (size_t)idx, (size_t)nb * 256); break;
+        case 0: split2h_rows(src, jobs.a[j], (unsigned short*)jobs.dst[j], (size_t)jobs.b[j], jobs.a[j], (size_t)idx, (size_t)nb * 256); break;
         case 1: prep_conv_w_bf16x3_elem(src, (unsigned short*)jobs.dst[j], jobs.a[j], jobs.b[j], idx); break;
         case 2: prep_conv_wT_bf16x3_elem(src, (unsigned short*)jobs.dst[j], jobs.a[j], jobs.b[j], idx); break;
         case 4: prep_conv_w_wino_bf16x3_elem(src, (unsigned short*)jobs.dst[j], jobs.a[j], jobs.b[j], idx); break;
         case 5: prep_conv_wT_wino_bf16x3_elem(src, (unsigned short*)jobs.dst[j], jobs.a[j], jobs.b[j], idx); break;
+        case 6: prep_conv_w_wino_f16x3_elem(src, (unsigned short*)jobs.dst[j], jobs.a[j], jobs.b[j], idx, jobs.status); break;
+        case 7: prep_conv_wT_wino_f16x3_elem(src, (unsigned short*)jobs.dst[j], jobs.a[j], jobs.b[j], idx, jobs.status); break;
         default: prep_whh_bwd_elem(src, (float*)jobs.dst[j], idx); break;
     }
 }
