@@ -1,4 +1,8 @@
-// Quad-workgroup GRU recurrence on the bf16 matrix cores (bf16x6 products, fp32 accuracy).
+// Quad-workgroup GRU recurrence on the matrix cores (fp32 accuracy).  Round 4: the products run on the fp16 cores with the
+// two-way split of f16_split.h ("f16x3": W = Wh + Wl' 2^-11, h = hh + hl' 2^-11; three products per fp32 product -- Wl' hh and
+// Wh hl' into one accumulator, Wh hh into another, folded as acc0 + 2^-11 acc1 -- instead of bf16x6's six): 72 instead of 144
+// MFMAs per wave and step, 192 instead of 288 resident weight registers, 2 instead of 3 h planes in LDS and in the granules.
+// h is in (-1, 1) and W_hh O(0.1): well inside fp16's range.  The description below is of the structure, unchanged since round 2:
 //
 // gru_pair_kernel computes W_hh h with fp32 FMAs and is bound by VALU issue (~64 us of FMA issue per
 // layer at batch 256 plus 25 dependent exchanges).  Here the recurrent product runs on MFMA:
@@ -13,7 +17,7 @@
 //   * h lives in LDS as three bf16 planes [utterance][k] (double-buffered by step parity, rows padded to
 //     528 B); every workgroup needs all 256 units, so after each step the four quarters exchange their
 //     64 x 16 new values through global memory: one 8-byte granule per value = {16-bit tag = launch epoch + step + 1,
-//     hi, mid, lo bf16}, written write-through (sc1, the code of an agent-scope relaxed atomic store) two granules per
+//     hi, lo' fp16, 16 spare bits}, written write-through (sc1, the code of an agent-scope relaxed atomic store) two granules per
 //     16-byte store, and polled with 16-byte sc1 loads until every tag matches (recipe R2 of cdna_hip_programming.md
 //     G16: the data is the flag -- each granule carries its own tag, so nothing depends on a pair landing together).
 //     Granule buffers alternate by step parity; a buffer is zeroed when new to the handle, not per launch.
@@ -27,7 +31,8 @@ constexpr int GQ_UQ = 64;                 // hidden units per workgroup
 constexpr int GQ_THREADS = 256;
 constexpr int GQ_ROWB = 256 * 2 + 16;     // bytes per utterance row of one h plane (pad: conflict-free b128 reads)
 constexpr int GQ_PLANEB = GQ_NU * GQ_ROWB;
-constexpr int GQ_BUFB = 3 * GQ_PLANEB;    // one parity buffer: 25,344 B
+constexpr int GQ_NPL = 2;                 // h planes: hi, scaled residual
+constexpr int GQ_BUFB = GQ_NPL * GQ_PLANEB;    // one parity buffer: 16,896 B
 constexpr size_t GQ_LDS_BYTES = 2 * (size_t)GQ_BUFB;
 constexpr unsigned GQ_SPIN_LIMIT = 1u << 22;
 constexpr int GQ_POLL_DELAY = 16;          // x 64 cycles between the granule stores and the first poll round (see the poll loop)
@@ -46,21 +51,20 @@ __device__ __forceinline__ float gq_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x));
 }
 
-// W_hh of one direction as the kernel's resident MFMA fragments: [quarter][wave][gate][k-step][plane][lane] uint4
+// W_hh of one direction as the kernel's resident MFMA fragments: [quarter][wave][gate][k-step][plane (hi, lo')][lane] uint4
 // (inference prepares this once per weights version; the kernel prologue is then 72 coalesced 16-byte loads per lane
-// instead of 48 row-strided fp32 loads and the three-way split)
+// instead of 48 row-strided fp32 loads and the split)
 static __global__ __launch_bounds__(256) void prep_whh_quad_kernel(const float* __restrict__ whh, uint4* __restrict__ frag) {
     const int idx = blockIdx.x * 256 + threadIdx.x;              // ((((q*4 + wv)*3 + g)*8 + s)*64 + lane)
     if (idx >= 4 * 4 * 3 * 8 * 64) return;
     const int lane = idx & 63, s = (idx >> 6) & 7, g = (idx >> 9) % 3, qw = idx / (64 * 8 * 3), wv = qw & 3, q = qw >> 2;
     const float* wrow = whh + (size_t)(g * 256 + q * 64 + wv * 16 + (lane & 15)) * 256 + s * 32 + (lane >> 4) * 8;
-    uint2 h0, m0, l0, h1, m1, l1;
-    split3_quad(*reinterpret_cast<const float4*>(wrow), h0, m0, l0);
-    split3_quad(*reinterpret_cast<const float4*>(wrow + 4), h1, m1, l1);
-    uint4* o = frag + ((size_t)(((qw * 3 + g) * 8 + s) * 3) * 64 + lane);
+    uint2 h0, l0, h1, l1;
+    split2h_quad(*reinterpret_cast<const float4*>(wrow), h0, l0);
+    split2h_quad(*reinterpret_cast<const float4*>(wrow + 4), h1, l1);
+    uint4* o = frag + ((size_t)(((qw * 3 + g) * 8 + s) * GQ_NPL) * 64 + lane);
     o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-    o[64] = make_uint4(m0.x, m0.y, m1.x, m1.y);
-    o[128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    o[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
 }
 
 // xbuf   [clusters][2 parity][4 quarters][16 utterances][64 units] 8-byte granules; the 16-bit tag is {7-bit launch epoch of
@@ -98,17 +102,17 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     const float* __restrict__ bhh = dir ? bhh1 : bhh0;
     unsigned long long* xc = xbuf + (size_t)cluster * (2 * 4 * GQ_NU * GQ_UQ);
 
-    // ---- resident weights: A fragments of the three gate tiles, bf16x3 planes --------------------------
-    bf16x8 wf[3][8][3];
+    // ---- resident weights: A fragments of the three gate tiles, f16x2 planes ----------------------------
+    f16x8 wf[3][8][GQ_NPL];
     const uint4* __restrict__ wfrag = dir ? wfrag1 : wfrag0;
     if (wfrag) {
-        const uint4* wsrc = wfrag + (size_t)((q * 4 + wv) * 3 * 8 * 3) * 64 + lane;
+        const uint4* wsrc = wfrag + (size_t)((q * 4 + wv) * 3 * 8 * GQ_NPL) * 64 + lane;
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
             for (int s = 0; s < 8; ++s)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) wf[g][s][p] = __builtin_bit_cast(bf16x8, wsrc[((g * 8 + s) * 3 + p) * 64]);
+                for (int p = 0; p < GQ_NPL; ++p) wf[g][s][p] = __builtin_bit_cast(f16x8, wsrc[((g * 8 + s) * GQ_NPL + p) * 64]);
     } else {
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
@@ -117,12 +121,11 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
         for (int s = 0; s < 8; ++s) {
             const float4 v0 = *reinterpret_cast<const float4*>(wrow + s * 32);
             const float4 v1 = *reinterpret_cast<const float4*>(wrow + s * 32 + 4);
-            uint2 h0, m0, l0, h1, m1, l1;
-            split3_quad(v0, h0, m0, l0);
-            split3_quad(v1, h1, m1, l1);
-            wf[g][s][0] = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
-            wf[g][s][1] = __builtin_bit_cast(bf16x8, make_uint4(m0.x, m0.y, m1.x, m1.y));
-            wf[g][s][2] = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+            uint2 h0, l0, h1, l1;
+            split2h_quad(v0, h0, l0);
+            split2h_quad(v1, h1, l1);
+            wf[g][s][0] = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+            wf[g][s][1] = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
         }
     }
     }
@@ -159,28 +162,32 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
         unsigned char* hnb = qlds + ((step + 1) & 1) * GQ_BUFB;
 
         // ---- W_hh h on the matrix cores ---------------------------------------------------------------
-        f32x4_t acc[3];
+        f32x4_t acc[3], accx[3];                             // accx: the two cross terms, 2^11 too large
 #pragma unroll
-        for (int g = 0; g < 3; ++g) acc[g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        // all 24 h fragments are read before the first MFMA (pinned): one wave per SIMD has nothing else to hide
+        for (int g = 0; g < 3; ++g) { acc[g] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; accx[g] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+        // all 16 h fragments are read before the first MFMA (pinned): one wave per SIMD has nothing else to hide
         // the LDS latency behind, and the compiler otherwise reads each fragment right before its use
-        bf16x8 hf[8][3];
+        f16x8 hf[8][GQ_NPL];
         if (!(dbg & 2)) {
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                hf[s][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(hb + p * GQ_PLANEB + frag_off + s * 64));
+            for (int p = 0; p < GQ_NPL; ++p)
+                hf[s][p] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(hb + p * GQ_PLANEB + frag_off + s * 64));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
 #pragma unroll
-            for (int t6 = 0; t6 < 6; ++t6)
+            for (int g = 0; g < 3; ++g) accx[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[g][s][1], hf[s][0], accx[g], 0, 0, 0);
 #pragma unroll
-                for (int g = 0; g < 3; ++g)
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g][s][PA[t6]], hf[s][PB[t6]], acc[g], 0, 0, 0);
+            for (int g = 0; g < 3; ++g) accx[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[g][s][0], hf[s][1], accx[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[g][s][0], hf[s][0], acc[g], 0, 0, 0);
         }
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[g][j] = fmaf(accx[g][j], H3_LO_INV, acc[g][j]);
         }
 
         // ---- gates for 4 units x 1 utterance ------------------------------------------------------------
@@ -202,23 +209,21 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
         hprev = make_float4(hn4[0], hn4[1], hn4[2], hn4[3]);
 
         // ---- publish: own LDS planes (next parity) + one granule per value for the three other quarters ----
-        uint2 ph, pm, pl;
-        split3_quad(hprev, ph, pm, pl);
+        uint2 ph, pl;
+        split2h_quad(hprev, ph, pl);
         {
             unsigned char* d = hnb + n * GQ_ROWB + u0 * 2;
             *reinterpret_cast<uint2*>(d) = ph;
-            *reinterpret_cast<uint2*>(d + GQ_PLANEB) = pm;
-            *reinterpret_cast<uint2*>(d + 2 * GQ_PLANEB) = pl;
+            *reinterpret_cast<uint2*>(d + GQ_PLANEB) = pl;
         }
         if (!(dbg & 4) && !((dbg & 8) && q == 3)) {
             unsigned long long* gs = xc + ((size_t)(step & 1) * 4 + q) * (GQ_NU * GQ_UQ) + xoff;
             const unsigned long long tag = (unsigned long long)((epoch << 9) | (unsigned)(step + 1)) << 48;
             const unsigned hh_[4] = {ph.x & 0xFFFFu, ph.x >> 16, ph.y & 0xFFFFu, ph.y >> 16};
-            const unsigned mm_[4] = {pm.x & 0xFFFFu, pm.x >> 16, pm.y & 0xFFFFu, pm.y >> 16};
             const unsigned ll_[4] = {pl.x & 0xFFFFu, pl.x >> 16, pl.y & 0xFFFFu, pl.y >> 16};
             unsigned long long gr[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) gr[j] = tag | ((unsigned long long)hh_[j] << 32) | ((unsigned long long)mm_[j] << 16) | ll_[j];
+            for (int j = 0; j < 4; ++j) gr[j] = tag | ((unsigned long long)hh_[j] << 32) | ((unsigned long long)ll_[j] << 16);
             // the lane's four granules go out as two 16-byte write-through stores (sc1 = what a relaxed agent-scope
             // atomic store compiles to) instead of four 8-byte ones -- half the store instructions and memory transactions
             // in front of the poll.  Every granule carries its own tag, so nothing depends on the pair landing together.
@@ -278,17 +283,14 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
 #pragma unroll
             for (int qi = 0; qi < 3; ++qi) {
                 const int qs = qi + (qi >= q ? 1 : 0);
-                uint2 rh, rm, rl;
+                uint2 rh, rl;
                 rh.x = (unsigned)((v[qi][0] >> 32) & 0xFFFFu) | ((unsigned)((v[qi][1] >> 32) & 0xFFFFu) << 16);
                 rh.y = (unsigned)((v[qi][2] >> 32) & 0xFFFFu) | ((unsigned)((v[qi][3] >> 32) & 0xFFFFu) << 16);
-                rm.x = (unsigned)((v[qi][0] >> 16) & 0xFFFFu) | ((unsigned)((v[qi][1] >> 16) & 0xFFFFu) << 16);
-                rm.y = (unsigned)((v[qi][2] >> 16) & 0xFFFFu) | ((unsigned)((v[qi][3] >> 16) & 0xFFFFu) << 16);
-                rl.x = (unsigned)(v[qi][0] & 0xFFFFu) | ((unsigned)(v[qi][1] & 0xFFFFu) << 16);
-                rl.y = (unsigned)(v[qi][2] & 0xFFFFu) | ((unsigned)(v[qi][3] & 0xFFFFu) << 16);
+                rl.x = (unsigned)((v[qi][0] >> 16) & 0xFFFFu) | ((unsigned)((v[qi][1] >> 16) & 0xFFFFu) << 16);
+                rl.y = (unsigned)((v[qi][2] >> 16) & 0xFFFFu) | ((unsigned)((v[qi][3] >> 16) & 0xFFFFu) << 16);
                 unsigned char* d = hnb + n * GQ_ROWB + (qs * GQ_UQ + (u0 - q * GQ_UQ)) * 2;
                 *reinterpret_cast<uint2*>(d) = rh;
-                *reinterpret_cast<uint2*>(d + GQ_PLANEB) = rm;
-                *reinterpret_cast<uint2*>(d + 2 * GQ_PLANEB) = rl;
+                *reinterpret_cast<uint2*>(d + GQ_PLANEB) = rl;
             }
         }
         // the stores of this step and the loads of the next one are issued only now: a hand-off costs what sits in the
@@ -298,10 +300,8 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
             *reinterpret_cast<float4*>(y + yidx) = hprev;
             if (yplanes) {
                 const size_t plane = (size_t)B * S * 512;
-                uint2 yh, yl;
-                split2h_quad(hprev, yh, yl);
-                *reinterpret_cast<uint2*>(yplanes + yidx) = yh;
-                *reinterpret_cast<uint2*>(yplanes + plane + yidx) = yl;
+                *reinterpret_cast<uint2*>(yplanes + yidx) = ph;          // (the planes this step published: the same split)
+                *reinterpret_cast<uint2*>(yplanes + plane + yidx) = pl;
             }
             if (SAVE) {
                 float* gsv = gates + (((size_t)b * S + t) * 2 + dir) * 1024 + u0;
