@@ -430,13 +430,21 @@ class _TimedIter:
     the DataLoader's worker start-up out)."""
 
     def __init__(self, it):
-        self.it, self.t_first, self.n_first, self.n = it, None, 0, 0
+        self.it, self.t_first, self.n_first, self.n, self.wait_s = it, None, 0, 0, 0.0
 
     def __iter__(self):
-        for item in self.it:
+        it = iter(self.it)
+        while True:
+            t0 = time.perf_counter()
+            try:
+                item = next(it)
+            except StopIteration:
+                return
+            t1 = time.perf_counter()
+            self.wait_s += t1 - t0                       # time the consumer spent waiting for the source to hand over a batch
             k = int(item[0].size(0)) if item[0] is not None else 0
             if self.t_first is None:
-                self.t_first, self.n_first = time.perf_counter(), k
+                self.t_first, self.n_first = t1, k
             self.n += k
             yield item
 
@@ -496,7 +504,7 @@ def dropin_epoch_leg(model, opt, fz, dev, step_rate, n_clips, batch=BATCH, worke
                 epoch_fn(it)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                best = {"utts_per_s": round(it.n / (t1 - t0), 1), "epoch_s": round(t1 - t0, 4),
+                best = {"utts_per_s": round(it.n / (t1 - t0), 1), "epoch_s": round(t1 - t0, 4), "waiting_for_batches_s": round(it.wait_s, 4),
                         "steady_utts_per_s": round((it.n - it.n_first) / max(t1 - it.t_first, 1e-9), 1),
                         "first_batch_after_s": round(it.t_first - t0, 4), "clips": it.n}
             best["frac_of_step_rate"] = round(best["utts_per_s"] / step_rate, 4)
@@ -524,9 +532,10 @@ def dropin_epoch_leg(model, opt, fz, dev, step_rate, n_clips, batch=BATCH, worke
         r["loader_only_utts_per_s"] = round(lo.n / (t1 - t0), 1)
         r["loader_only_steady_utts_per_s"] = round((lo.n - lo.n_first) / max(t1 - lo.t_first, 1e-9), 1)
         r["cache_load_s"] = round(load_s, 3)
-        r["limit"] = ("host batch assembly (worker __getitem__ + collate_fn + pinned copy + H2D): the loader alone delivers "
-                      f"{r['loader_only_steady_utts_per_s']:.0f} utt/s" if r["loader_only_steady_utts_per_s"] < 1.15 * r["steady_utts_per_s"]
-                      else "the GPU step")
+        r["limit"] = ("host batch assembly (worker __getitem__ + collate_fn + pinned copy + H2D): "
+                      f"{r['waiting_for_batches_s']:.2f} s of the {r['epoch_s']:.2f} s epoch are spent waiting for the DataLoader to hand over a "
+                      f"batch; the loader alone, with an idle main thread, delivers {r['loader_only_steady_utts_per_s']:.0f} utt/s"
+                      if r["waiting_for_batches_s"] > 0.5 * r["epoch_s"] else "the GPU step")
         out["dataloader"] = r
         del ds
         # ---- route 2: the cache staged in HBM (train()'s default) ----

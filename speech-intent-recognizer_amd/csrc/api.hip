@@ -35,7 +35,7 @@ static int upload(T** dst, const std::vector<T>& src) {
 }
 
 int sir_wino2_mask() {
-    static const int m = getenv("SIR_WINO2") ? atoi(getenv("SIR_WINO2")) : 7;
+    static const int m = getenv("SIR_WINO2") ? atoi(getenv("SIR_WINO2")) : 15;
     return m;
 }
 
@@ -50,7 +50,7 @@ int sir_tn2_mask() {
 }
 
 int sir_f16_mask() {
-    static const int m = getenv("SIR_F16") ? atoi(getenv("SIR_F16")) : 3;
+    static const int m = getenv("SIR_F16") ? atoi(getenv("SIR_F16")) : 63;
     return m;
 }
 

@@ -26,14 +26,41 @@ constexpr int TN2_THREADS = 64 * (TN2_NPW + 8);              // + 8 consumer wav
 constexpr int TN2_BM = 128;
 constexpr size_t tn2_lds_bytes(bool a_km, int bm = TN2_BM) { return 2 * tn_lds_bytes(a_km, bm); }     // two stage buffers: 147,456 / 159,744 B (BM = 128)
 
+// F16 (round 4): the products on the fp16 matrix cores with the two-way split of f16_split.h.  A (the gate gradients, which carry the
+// backward's loss scale and therefore sit in fp16's range) is staged as TWO planes (Ah, Al' = residual 2^11); B (activations / weights)
+// is first scaled by TN2_BS = 2^-4 (exact) and staged as THREE planes (Bh, Bh 2^11, Bl'), so that the three products
+// Al' Bh + Ah Bl' + Ah (Bh 2^11) = 2^11 A B go into ONE accumulator (the consumers' 64 accumulator registers are what the 128-register
+// budget of a 1024-thread workgroup allows) and the epilogue scales by 2^-11 / TN2_BS = 2^-7.  Bh 2^11 is exact while |B| TN2_BS < 32,
+// i.e. |B| < 512 (larger values are clamped: activations behind BatchNorm and weights are nowhere near).  3 instead of 6 MFMAs per
+// product, 5 instead of 6 planes through LDS, a shorter split.
+constexpr float TN2_BS = 0.0625f;
+constexpr float TN2_BLIM = 31.984375f;                       // 65504 / 2048
+// (Bh, Bh 2^11, Bl') of v * SCALE (SCALE a power of two, |v| SCALE clamped below 32)
+template <int SCALE_LOG2 = -4>
+__device__ __forceinline__ void tn2_split_b(const float4& v, uint2& hh, uint2& h2, uint2& ll) {
+    constexpr float SC = SCALE_LOG2 >= 0 ? (float)(1 << (SCALE_LOG2 >= 0 ? SCALE_LOG2 : 0)) : 1.0f / (float)(1 << (SCALE_LOG2 < 0 ? -SCALE_LOG2 : 0));
+    auto pair = [](float a, float b, unsigned& h, unsigned& hs, unsigned& l) {
+        sir_f32x2 x = {__builtin_fminf(__builtin_fmaxf(a * SC, -TN2_BLIM), TN2_BLIM), __builtin_fminf(__builtin_fmaxf(b * SC, -TN2_BLIM), TN2_BLIM)};
+        const sir_f16x2 hi = __builtin_convertvector(x, sir_f16x2);
+        x -= __builtin_convertvector(hi, sir_f32x2);
+        x *= H3_LO_SCALE;
+        const sir_f16x2 lo = __builtin_convertvector(x, sir_f16x2);
+        const sir_f16x2 his = hi * (sir_f16x2){(_Float16)2048.0f, (_Float16)2048.0f};          // exact: |hi| < 32
+        h = __builtin_bit_cast(unsigned, hi); hs = __builtin_bit_cast(unsigned, his); l = __builtin_bit_cast(unsigned, lo);
+    };
+    pair(v.x, v.y, hh.x, h2.x, ll.x);
+    pair(v.z, v.w, hh.y, h2.y, ll.y);
+}
+
 __device__ __forceinline__ void tn2_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool A_KM, int dbg = 0, int BM = TN2_BM>
+template <bool A_KM, int dbg = 0, int BM = TN2_BM, bool F16 = false>
 __global__ __launch_bounds__(TN2_THREADS, TN2_THREADS / 256) void gemm_tn2_bf16x6_kernel(TnJobs jobs, int M, int K, int kchunk, int seq) {
     constexpr int NC = BM >= 128 ? 2 : 1;                    // BM = 128: consumers 2 x 4, wave tile 64 x 64; BM = 64: 1 x 8, wave tile 64 x 32
     constexpr int AXW = BM * 2, BXW = TN_BN * 2;             // row bytes of the k-major images
     constexpr int APLANE = A_KM ? TN_BK * AXW : BM * TN_ROWB, BPLANE = TN_BK * BXW;
-    constexpr int STAGE = 3 * APLANE + 3 * BPLANE;
+    constexpr int NPA = F16 ? 2 : 3;                         // planes of A (B: three in both arithmetics)
+    constexpr int STAGE = NPA * APLANE + 3 * BPLANE;
     constexpr int NPT = 64 * TN2_NPW;                         // producer threads
     constexpr int NAQ = BM * 8 / NPT, NBQ = TN_BN * 8 / NPT;  // staging items per PRODUCER thread
     extern __shared__ __attribute__((aligned(16))) unsigned char tl2[];
@@ -131,19 +158,27 @@ __global__ __launch_bounds__(TN2_THREADS, TN2_THREADS / 256) void gemm_tn2_bf16x
 #pragma unroll
             for (int q = 0; q < NAQ; ++q) {
                 const int it = ptid + NPT * q;
-                uint2 hh, mm, ll;
-                split3_quad(pa[q], hh, mm, ll);
                 unsigned char* d = A_KM ? AT + tn_kmaj_off<AXW>(it / (BM / 4), 8 * (it % (BM / 4)))
                                         : AT + (size_t)(it >> 3) * TN_ROWB + (it & 7) * 8;
-                *reinterpret_cast<uint2*>(d) = hh;
-                *reinterpret_cast<uint2*>(d + APLANE) = mm;
-                *reinterpret_cast<uint2*>(d + 2 * APLANE) = ll;
+                if constexpr (F16) {
+                    uint2 hh, ll;
+                    split2h_quad(pa[q], hh, ll);
+                    *reinterpret_cast<uint2*>(d) = hh;
+                    *reinterpret_cast<uint2*>(d + APLANE) = ll;
+                } else {
+                    uint2 hh, mm, ll;
+                    split3_quad(pa[q], hh, mm, ll);
+                    *reinterpret_cast<uint2*>(d) = hh;
+                    *reinterpret_cast<uint2*>(d + APLANE) = mm;
+                    *reinterpret_cast<uint2*>(d + 2 * APLANE) = ll;
+                }
             }
 #pragma unroll
             for (int q = 0; q < NBQ; ++q) {
                 const int it = ptid + NPT * q;
                 uint2 hh, mm, ll;
-                split3_quad(pb[q], hh, mm, ll);
+                if constexpr (F16) tn2_split_b(pb[q], hh, mm, ll);     // (Bh, Bh 2^11, Bl') of B / 16
+                else split3_quad(pb[q], hh, mm, ll);
                 unsigned char* d = BT + tn_kmaj_off<BXW>(it >> 6, 8 * (it & 63));
                 *reinterpret_cast<uint2*>(d) = hh;
                 *reinterpret_cast<uint2*>(d + BPLANE) = mm;
@@ -154,10 +189,10 @@ __global__ __launch_bounds__(TN2_THREADS, TN2_THREADS / 256) void gemm_tn2_bf16x
 #pragma unroll 1
         for (int s = 0; s < 2 * npair; s += 2) {
             if (!(dbg & 2)) fetch(k_begin + (s + 1) * TN_BK, pa1, pb1);     // a whole step ahead, in flight across the barrier
-            if (!(dbg & 1)) stage(tl2, tl2 + 3 * APLANE, pa0, pb0);         // (past the last stage: zeros into the idle buffer)
+            if (!(dbg & 1)) stage(tl2, tl2 + NPA * APLANE, pa0, pb0);       // (past the last stage: zeros into the idle buffer)
             tn2_barrier();
             if (!(dbg & 2)) fetch(k_begin + (s + 2) * TN_BK, pa0, pb0);
-            if (!(dbg & 1)) stage(tl2 + STAGE, tl2 + STAGE + 3 * APLANE, pa1, pb1);
+            if (!(dbg & 1)) stage(tl2 + STAGE, tl2 + STAGE + NPA * APLANE, pa1, pb1);
             tn2_barrier();
         }
         return;
@@ -179,7 +214,7 @@ __global__ __launch_bounds__(TN2_THREADS, TN2_THREADS / 256) void gemm_tn2_bf16x
     for (int a = 0; a < 2; ++a)
         aoff[a] = A_KM ? tn_kmaj_off<AXW>(tk, 2 * (wm * 64 + a * 32 + tcol)) : (wm * 64 + a * 32 + i32) * TN_ROWB + kgrp * 16;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) boff[c] = 3 * APLANE + tn_kmaj_off<BXW>(tk, 2 * (wn * 32 * NC + c * 32 + tcol));
+    for (int c = 0; c < NC; ++c) boff[c] = NPA * APLANE + tn_kmaj_off<BXW>(tk, 2 * (wn * 32 * NC + c * 32 + tcol));
     tn2_barrier();                                           // step 0: the producers write stage 0
 #pragma unroll 1
     for (int s = 1; s <= nst; ++s) {
@@ -187,24 +222,39 @@ __global__ __launch_bounds__(TN2_THREADS, TN2_THREADS / 256) void gemm_tn2_bf16x
         if (dbg & 16) { tn2_barrier(); continue; }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2][3], bf[NC][3];
+            bf16x8 af[2][NPA], bf[NC][3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
+                if (p < NPA) {
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-                    af[a][p] = A_KM ? tn_tr_fragment<AXW>(sb + aoff[a] + p * APLANE + ks * 16 * AXW)
-                                    : __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + aoff[a] + p * APLANE + ks * 32));
+                    for (int a = 0; a < 2; ++a)
+                        af[a][p < NPA ? p : 0] = A_KM ? tn_tr_fragment<AXW>(sb + aoff[a] + p * APLANE + ks * 16 * AXW)
+                                                      : __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + aoff[a] + p * APLANE + ks * 32));
+                }
 #pragma unroll
                 for (int c = 0; c < NC; ++c) bf[c][p] = tn_tr_fragment<BXW>(sb + boff[c] + p * BPLANE + ks * 16 * BXW);
             }
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
+            if constexpr (F16) {
+                // af: 0 = Ah, 1 = Al'; bf: 0 = Bh, 1 = Bh 2^11, 2 = Bl' -- the two cross terms first, then the main one
+                constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 2, 1};
 #pragma unroll
-            for (int t6 = 0; t6 < 6; ++t6)
+                for (int t3 = 0; t3 < 3; ++t3)
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+                    for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int c = 0; c < NC; ++c)
-                        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA[t6]], bf[c][PB[t6]], acc[a][c], 0, 0, 0);
+                        for (int c = 0; c < NC; ++c)
+                            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[a][HA[t3]]), __builtin_bit_cast(f16x8, bf[c][HB[t3]]),
+                                                                              acc[a][c], 0, 0, 0);
+            } else {
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
+#pragma unroll
+                for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+                            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA[t6] % NPA], bf[c][PB[t6]], acc[a][c], 0, 0, 0);
+            }
         }
         tn2_barrier();
     }
@@ -220,7 +270,7 @@ __global__ __launch_bounds__(TN2_THREADS, TN2_THREADS / 256) void gemm_tn2_bf16x
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
                 if (m < M) {
-                    float v = acc[a][c][r];
+                    float v = acc[a][c][r] * (F16 ? H3_LO_INV / TN2_BS : 1.0f);
                     if (jobs.drop_p > 0.0f) v = tn_dropout_keep(jobs.drop_seed, (size_t)m * N + n, jobs.drop_p) ? v * (1.0f / (1.0f - jobs.drop_p)) : 0.0f;
                     out[(size_t)m * N + n] = v;
                 }

@@ -131,8 +131,8 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     n[TB_SLAB] = slab + (size_t)WGR_PARTS * 16 * 128 * 64;      // + the partial sums of the two-pass wgrad reduce
     n[TB_XS] = (B * S * 1024 * 2 + 1) / 2;                       // ushort count / 2 (sizes are in floats)
     n[TB_WS] = ((size_t)2 * 2 * 768 * 1024 + (size_t)2 * 2 * 768 * 512 + 1) / 2;
-    // conv2 forward and the conv3 data gradient in Winograd form (16 frequencies), conv3 forward and the conv2 data gradient direct (9 taps)
-    n[TB_WCB] = ((size_t)(3 * 32 * 16 * 64 + 3 * 32 * 9 * 64) + (size_t)3 * 64 * 16 * 128 + (size_t)3 * 128 * 16 * 64 + (size_t)3 * 64 * 9 * 128 + 1) / 2;
+    // conv2 / conv3 forward and both data gradients in Winograd form (16 frequencies; the conv2 data gradient's slot also holds its 9-tap form when the direct kernel runs it), conv3 forward again with 9 taps for the direct fallback
+    n[TB_WCB] = ((size_t)(3 * 32 * 16 * 64 + 3 * 32 * 16 * 64) + (size_t)3 * 64 * 16 * 128 + (size_t)3 * 128 * 16 * 64 + (size_t)3 * 64 * 9 * 128 + 1) / 2;
     n[TB_GXB] = 64;
     n[TB_GFL] = 64;
     n[TB_C1M] = 2 * C1_NMOM;
@@ -180,7 +180,7 @@ TPtrs carve(void* ws, const size_t* off) {
     p.xs = (unsigned short*)(b + off[TB_XS]);
     p.wsl0 = (unsigned short*)(b + off[TB_WS]); p.wsl1 = p.wsl0 + (size_t)2 * 2 * 768 * 1024;
     p.wcb2 = (unsigned short*)(b + off[TB_WCB]); p.wcb3 = p.wcb2 + (size_t)3 * 32 * 16 * 64;
-    p.wcb2t = p.wcb3 + (size_t)3 * 64 * 16 * 128; p.wcb3t = p.wcb2t + (size_t)3 * 32 * 9 * 64;
+    p.wcb2t = p.wcb3 + (size_t)3 * 64 * 16 * 128; p.wcb3t = p.wcb2t + (size_t)3 * 32 * 16 * 64;
     p.wcb3d = p.wcb3t + (size_t)3 * 128 * 16 * 64;           // conv3 forward with 9 taps: only for shapes the Winograd kernel does not cover
     p.gfl = (unsigned int*)(b + off[TB_GFL]);
     p.c1m = (double*)(b + off[TB_C1M]);
@@ -198,6 +198,18 @@ int check_common(const char* who, sir_handle* h, const sir_model_weights* w, int
     if (bytes < need) { sir_set_error("%s: workspace %zu < %zu", who, bytes, need); return SIR_ENOMEM; }
     if (((uintptr_t)ws & 255) != 0) { sir_set_error("%s: workspace must be 256-byte aligned", who); return SIR_EINVAL; }
     return SIR_OK;
+}
+
+// Loss scale of the backward (a power of two, exact in fp32 both ways): head_bwd_kernel multiplies d(loss)/d(GRU output) by it and
+// every kernel that writes a PARAMETER gradient behind it multiplies by its inverse, so that the intermediate gradients -- 1e-5 to
+// 1e-7 at batch 256 unscaled -- sit around 2^-4 .. 2^4: inside fp16's normal range for the f16x3 contractions of the backward
+// (f16_split.h), with 2^10 of head room on either side.  2^8 x batch (rounded up to a power of two) makes the scaled d(logits)
+// (softmax - onehot) x 2^8 whatever the batch.  Results are bit-identical to the unscaled backward wherever the arithmetic is fp32
+// or bf16x6 (scaling by 2^k commutes with every rounding there).
+inline float sir_bwd_loss_scale(int batch) {
+    int k = 8;
+    while ((1 << (k - 8)) < batch && k < 24) ++k;
+    return (float)(1u << k);
 }
 
 inline int grid_for(size_t n, int per_block = 256, int cap = 8192) {
@@ -257,8 +269,18 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
         add(f16c2 ? 6 : 4, w->conv_w[1], p.wcb2, 32, 64, (32 * 16 * 64 + 255) / 256);       // conv2 forward: Winograd frequencies
         add(f16c3 ? 6 : 4, w->conv_w[2], p.wcb3, 64, 128, (64 * 16 * 128 + 255) / 256);     // conv3 forward: Winograd frequencies
         if (!w2c3) add(1, w->conv_w[2], p.wcb3d, 64, 128, (64 * 9 * 128 + 255) / 256);
-        add(2, w->conv_w[1], p.wcb2t, 32, 64, (32 * 9 * 64 + 255) / 256);
-        add(5, w->conv_w[2], p.wcb3t, 64, 128, (128 * 16 * 64 + 255) / 256);   // conv3 data gradient: Winograd frequencies of the flipped taps
+        {   // conv2 data gradient (64 -> 32): the second-generation Winograd kernel on f16x3 (its transform feeds only 32 outputs -- on
+            // bf16x6 that lost to the direct kernel, with half the matrix products it wins: profiles/r04/bench_conv_f16x3.txt), else direct
+            Wino2Geo geo2b;
+            const bool f16d2 = wino2_geo(B, 32, d.wp1, 64, &geo2b) && (sir_wino2_mask() & 8) && (sir_f16_mask() & 16);
+            if (f16d2) add(7, w->conv_w[1], p.wcb2t, 32, 64, (64 * 16 * 32 + 255) / 256);
+            else add(2, w->conv_w[1], p.wcb2t, 32, 64, (32 * 9 * 64 + 255) / 256);
+        }
+        {   // conv3 data gradient: Winograd frequencies of the flipped taps (f16x3 planes when that stage runs on them)
+            Wino2Geo geo3b;
+            const bool f16d3 = wino2_geo(B, 16, d.wp2, 128, &geo3b) && (sir_wino2_mask() & 4) && (sir_f16_mask() & 4);
+            add(f16d3 ? 7 : 5, w->conv_w[2], p.wcb3t, 64, 128, (128 * 16 * 64 + 255) / 256);
+        }
         for (int dir = 0; dir < 2; ++dir) {
             add(0, w->gru_w_ih[dir], p.wsl0 + (size_t)dir * 2 * 768 * 1024, 1024, 768, 384);
             add(0, w->gru_w_ih[2 + dir], p.wsl1 + (size_t)dir * 2 * 768 * 512, 512, 768, 192);
@@ -406,6 +428,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
     float* bsum_i = p.slab;                              // [B][1536] x2, consumed before the slabs are used
     float* bsum_h = p.slab + (size_t)B * 1536;
     const float* y0in = dropout_p > 0.0f ? p.y0d : p.y0;
+    const float gscale = sir_bwd_loss_scale(B), unscale = 1.0f / gscale;
 
     // ---- two-stream form (SIR_BWD_STREAMS=1; A/B in profiles/r04/ab_bwd_streams.txt) ----------------------------------------
     // The four big launches that nothing downstream waits for -- the GRU weight gradients of both layers and the two convolution
@@ -425,6 +448,9 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn2_bf16x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn2_lds_bytes(true)));
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn2_bf16x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn2_lds_bytes(false)));
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn2_bf16x6_kernel<false, 0, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn2_lds_bytes(false, 64)));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn2_bf16x6_kernel<true, 0, TN2_BM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn2_lds_bytes(true)));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn2_bf16x6_kernel<false, 0, TN2_BM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn2_lds_bytes(false)));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn2_bf16x6_kernel<false, 0, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn2_lds_bytes(false, 64)));
         h->attr_tn = true;
     }
     const bool two = sir_bwd_streams() && h->bwd_side != nullptr;
@@ -470,13 +496,15 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             jb.slab_stride[j] = sizes[j];
             pos += sizes[j] * nsplit;
         }
-        if (tn2_dw)
+        if (tn2_dw && (sir_f16_mask() & 8))                     // f16x3: the gate gradients carry the loss scale
+            hipLaunchKernelGGL((gemm_tn2_bf16x6_kernel<true, 0, TN2_BM, true>), dim3(tiles, nsplit), dim3(TN2_THREADS), tn2_lds_bytes(true), s_, jb, 768, M, kchunk, S);
+        else if (tn2_dw)
             hipLaunchKernelGGL(gemm_tn2_bf16x6_kernel<true>, dim3(tiles, nsplit), dim3(TN2_THREADS), tn2_lds_bytes(true), s_, jb, 768, M, kchunk, S);
         else
             hipLaunchKernelGGL((gemm_tn_bf16x6_kernel<true, TN_BM_DW>), dim3(tiles, nsplit), dim3(512), tn_lds_bytes(true, TN_BM_DW), s_, jb, 768, M, kchunk, S);
         SlabJobs sj{};
         for (int j = 0; j < 4; ++j) { sj.src[j] = jb.slab[j]; sj.out[j] = outs[j]; sj.n[j] = sizes[j]; }
-        hipLaunchKernelGGL(slab_reduce_jobs_kernel, dim3(grid_for(sizes[0]), 4), dim3(256), 0, s_, sj, nsplit);
+        hipLaunchKernelGGL(slab_reduce_jobs_kernel, dim3(grid_for(sizes[0]), 4), dim3(256), 0, s_, sj, nsplit, unscale);
         return SIR_OK;
     };
 
@@ -484,7 +512,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
     // ---- head: fc + attention pooling ----------------------------------------------------
     { SirProfScope prof(h, SIR_K_B_HEAD, st);
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B + 2 * C), dim3(256), 0, st, dlogits, w->fc_w, (const float*)p.y1, w->attn_w, w->attn_b,
-                       (const float*)p.ctx, p.dy1, daw_part, dab_part, g->fc_w, g->fc_b, B, S, C);
+                       (const float*)p.ctx, p.dy1, daw_part, dab_part, g->fc_w, g->fc_b, B, S, C, gscale);
     hipLaunchKernelGGL(head_colsum_kernel, dim3(9), dim3(256), 0, st, (const float*)daw_part, (const float*)dab_part, B, g->attn_w, g->attn_b); }
     KCHECK();
 
@@ -504,7 +532,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP;
         // bias gradients first: bsum_* alias the slab area used below
         hipLaunchKernelGGL(gru_bias_colsum_kernel, dim3(24, 2), dim3(256), 0, st, (const float*)bsum_i, (const float*)bsum_h, B,
-                           g->gru_b_ih[2 * layer], g->gru_b_ih[2 * layer + 1], g->gru_b_hh[2 * layer], g->gru_b_hh[2 * layer + 1]); }
+                           g->gru_b_ih[2 * layer], g->gru_b_ih[2 * layer + 1], g->gru_b_hh[2 * layer], g->gru_b_hh[2 * layer + 1], unscale); }
         if (!defer_dw) { rc = launch_dw(layer, st); if (rc != SIR_OK) return rc; }
         // gradient wrt the layer input: dgi [M][1536] x [W_ih; W_ih_reverse] [1536][in]
         SirProfScope prof(h, layer ? SIR_K_B_DX1 : SIR_K_B_DX0, st);
@@ -525,20 +553,27 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                 jn.drop_p = 0.0f;                                // (the dropout mask is applied by the add)
                 jn.slab[0] = p.slab; jn.slab_stride[0] = (size_t)M * in_sz;
                 jn.tile0[1] = ntiles;
-                hipLaunchKernelGGL(gemm_tn2_bf16x6_kernel<false>, dim3(ntiles, 2), dim3(TN2_THREADS), tn2_lds_bytes(false), st, jn, M, 1536, 768, 1);
+                if (sir_f16_mask() & 8)
+                    hipLaunchKernelGGL((gemm_tn2_bf16x6_kernel<false, 0, TN2_BM, true>), dim3(ntiles, 2), dim3(TN2_THREADS), tn2_lds_bytes(false), st, jn, M, 1536, 768, 1);
+                else
+                    hipLaunchKernelGGL(gemm_tn2_bf16x6_kernel<false>, dim3(ntiles, 2), dim3(TN2_THREADS), tn2_lds_bytes(false), st, jn, M, 1536, 768, 1);
                 const bool drop = layer == 1 && dropout_p > 0.0f;
                 hipLaunchKernelGGL(dx_halves_add_kernel, dim3(grid_for((size_t)M * in_sz / 4)), dim3(256), 0, st, (const float*)p.slab, (size_t)M * in_sz / 4,
                                    dxin, drop ? dropout_p : 0.0f, (unsigned long long)dropout_seed);
             } else if (ntiles < 160) {                       // too few 128-row tiles to fill the CUs: 64-row tiles
                 ntiles = ((M + 63) / 64) * ntn;
                 jn.tile0[1] = ntiles;
-                if (sir_tn2_mask() & 4)
+                if ((sir_tn2_mask() & 4) && (sir_f16_mask() & 8))
+                    hipLaunchKernelGGL((gemm_tn2_bf16x6_kernel<false, 0, 64, true>), dim3(ntiles, 1), dim3(TN2_THREADS), tn2_lds_bytes(false, 64), st, jn, M, 1536, 1536, 1);
+                else if (sir_tn2_mask() & 4)
                     hipLaunchKernelGGL((gemm_tn2_bf16x6_kernel<false, 0, 64>), dim3(ntiles, 1), dim3(TN2_THREADS), tn2_lds_bytes(false, 64), st, jn, M, 1536, 1536, 1);
                 else
                     hipLaunchKernelGGL((gemm_tn_bf16x6_kernel<false, 64>), dim3(ntiles, 1), dim3(512), TN_LDS_BYTES_64, st, jn, M, 1536, 1536, 1);
             } else {
                 jn.tile0[1] = ntiles;
-                if (sir_tn2_mask() & 2)
+                if ((sir_tn2_mask() & 2) && (sir_f16_mask() & 8))
+                    hipLaunchKernelGGL((gemm_tn2_bf16x6_kernel<false, 0, TN2_BM, true>), dim3(ntiles, 1), dim3(TN2_THREADS), tn2_lds_bytes(false), st, jn, M, 1536, 1536, 1);
+                else if (sir_tn2_mask() & 2)
                     hipLaunchKernelGGL(gemm_tn2_bf16x6_kernel<false>, dim3(ntiles, 1), dim3(TN2_THREADS), tn2_lds_bytes(false), st, jn, M, 1536, 1536, 1);
                 else
                     hipLaunchKernelGGL(gemm_tn_bf16x6_kernel<false>, dim3(ntiles, 1), dim3(512), TN_LDS_BYTES, st, jn, M, 1536, 1536, 1);
@@ -567,6 +602,8 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_wino_bf16x6_kernel<64, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgwCfg<64, 128>::lds_bytes));
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_wino_bf16x6_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgwCfg<32, 64>::lds_bytes));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_wino_bf16x6_kernel<64, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgwCfg<64, 128>::lds_bytes));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_wino_bf16x6_kernel<32, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgwCfg<32, 64>::lds_bytes));
         h->attr_wgrad = true;
     }
     {
@@ -579,7 +616,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                                (const float*)p.z3, w->bn_w[2], w->bn_b[2], scale + 96, shift + 96, smean + 96, sinv + 96, p.stats, rows,
                                16, d.wp2, d.wp3, rpb);
             hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(128), dim3(256), 0, st, (const float2*)p.stats, nfin, 128,
-                               (double)B * 16 * d.wp2, g->bn_w[2], g->bn_b[2], mdy + 96, mdyx + 96);
+                               (double)B * 16 * d.wp2, g->bn_w[2], g->bn_b[2], mdy + 96, mdyx + 96, unscale);
             hipLaunchKernelGGL(bn_bwd_dz_kernel<true>, dim3(grid_for((size_t)B * 8 * ((d.wp2 + 1) / 2) * 32)), dim3(256), 0, st, (const float*)p.z3,
                                (const float*)p.dx0, scale + 96, shift + 96, smean + 96, sinv + 96, mdy + 96, mdyx + 96, p.dz3, B, 16,
                                d.wp2, 128, 8, d.wp3);
@@ -594,12 +631,16 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                 // Winograd form: 16 products per tile and channel pair instead of 36 (wgrad_wino_bf16x6_kernel.h)
                 using Cfg3 = WgwCfg<64, 128>;
                 const int strips = wgrad_wino_strips(B, 16, d.wp2, Cfg3::TPS, Cfg3::groups, h->num_cus);
+                if (sir_f16_mask() & 32)
+                    hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<64, 128, true>), dim3(Cfg3::groups * strips), dim3(WGW_THREADS), Cfg3::lds_bytes, side,
+                                       (const float*)p.dz3, (const float*)p.a2, p.slab, B, 16, d.wp2);
+                else
                 hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<64, 128>), dim3(Cfg3::groups * strips), dim3(WGW_THREADS), Cfg3::lds_bytes, side,
                                    (const float*)p.dz3, (const float*)p.a2, p.slab, B, 16, d.wp2);
                 float* part = p.slab + (size_t)strips * 16 * 128 * 64;
                 hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((16 * 128 * 64 / 4 + 255) / 256), dim3(256), 0, side, (const float*)p.slab, strips,
                                    16 * 128 * 64 / 4, part);
-                hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((128 * 64 + 255) / 256), dim3(256), 0, side, (const float*)part, 64, 128, g->conv_w[2]);
+                hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((128 * 64 + 255) / 256), dim3(256), 0, side, (const float*)part, 64, 128, g->conv_w[2], unscale);
             } else {
             const size_t ldsx = wgrad_x6_lds_bytes(64, 128, d.wp2);
             if (ldsx > 160 * 1024 || d.wp2 > wgrad_x6_max_w(128)) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
@@ -610,7 +651,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             hipLaunchKernelGGL(wgrad_reduce_partial_kernel, dim3((9 * 128 * 64 / 4 + 255) / 256, WGR_PARTS), dim3(256), 0, side,
                                (const float*)p.slab, nslab3, 9 * 128 * 64 / 4, part);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 128 * 64 + 255) / 256), dim3(256), 0, side, (const float*)part, WGR_PARTS, 64, 128,
-                               g->conv_w[2]);
+                               g->conv_w[2], unscale);
             }
         }
         {
@@ -618,7 +659,10 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             // of 8 x 4 tiles for the 16-row map, raw output (train_prep_kernel of the forward built p.wcb3t)
             SirProfScope prof(h, SIR_K_B_DGRAD3, st);
             Wino2Geo geo3b;
-            if (wino2_geo(B, 16, d.wp2, 128, &geo3b) && (sir_wino2_mask() & 4))
+            if (wino2_geo(B, 16, d.wp2, 128, &geo3b) && (sir_wino2_mask() & 4) && (sir_f16_mask() & 4))     // dz3 carries the loss scale: inside fp16's range
+                SIR_HIP_TRY((launch_conv_wino2<128, 64, 3, 0, 3, true>(st, &h->attr_wino2[9], (const float*)p.dz3, (const unsigned short*)p.wcb3t, (const float*)nullptr,
+                                                                     (const float*)nullptr, p.da2, B, 16, d.wp2, (float2*)nullptr, h->zero_page, h->num_cus)));
+            else if (wino2_geo(B, 16, d.wp2, 128, &geo3b) && (sir_wino2_mask() & 4))
                 SIR_HIP_TRY((launch_conv_wino2<128, 64, 3>(st, &h->attr_wino2[4], (const float*)p.dz3, (const unsigned short*)p.wcb3t, (const float*)nullptr,
                                                          (const float*)nullptr, p.da2, B, 16, d.wp2, (float2*)nullptr, h->zero_page, h->num_cus)));
             else
@@ -639,7 +683,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                                (const float*)p.z2, w->bn_w[1], w->bn_b[1], scale + 32, shift + 32, smean + 32, sinv + 32, p.stats, B, 32,
                                d.wp1, 64, 16, d.wp2, ppb);
             hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(64), dim3(256), 0, st, (const float2*)p.stats, nblk, 64,
-                               (double)B * 32 * d.wp1, g->bn_w[1], g->bn_b[1], mdy + 32, mdyx + 32);
+                               (double)B * 32 * d.wp1, g->bn_w[1], g->bn_b[1], mdy + 32, mdyx + 32, unscale);
             hipLaunchKernelGGL(bn_bwd_dz_kernel<false>, dim3(grid_for((size_t)B * 16 * ((d.wp1 + 1) / 2) * 16)), dim3(256), 0, st, (const float*)p.z2,
                                (const float*)p.da2, scale + 32, shift + 32, smean + 32, sinv + 32, mdy + 32, mdyx + 32, p.dz2, B, 32,
                                d.wp1, 64, 16, d.wp2);
@@ -653,12 +697,16 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             if ((sir_wgw_mask() & 1) && (size_t)B * 32 * d.wp1 * 64 * 4 < ((size_t)1 << 31)) {
                 using Cfg2 = WgwCfg<32, 64>;
                 const int strips = wgrad_wino_strips(B, 32, d.wp1, Cfg2::TPS, Cfg2::groups, h->num_cus);
+                if (sir_f16_mask() & 32)
+                    hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<32, 64, true>), dim3(Cfg2::groups * strips), dim3(WGW_THREADS), Cfg2::lds_bytes, side,
+                                       (const float*)p.dz2, (const float*)p.a1, p.slab, B, 32, d.wp1);
+                else
                 hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<32, 64>), dim3(Cfg2::groups * strips), dim3(WGW_THREADS), Cfg2::lds_bytes, side,
                                    (const float*)p.dz2, (const float*)p.a1, p.slab, B, 32, d.wp1);
                 float* part = p.slab + (size_t)strips * 16 * 64 * 32;
                 hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((16 * 64 * 32 / 4 + 255) / 256), dim3(256), 0, side, (const float*)p.slab, strips,
                                    16 * 64 * 32 / 4, part);
-                hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((64 * 32 + 255) / 256), dim3(256), 0, side, (const float*)part, 32, 64, g->conv_w[1]);
+                hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((64 * 32 + 255) / 256), dim3(256), 0, side, (const float*)part, 32, 64, g->conv_w[1], unscale);
             } else {
             const size_t ldsx = wgrad_x6_lds_bytes(32, 64, d.wp1);
             if (ldsx > 160 * 1024 || d.wp1 > wgrad_x6_max_w(64)) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
@@ -669,12 +717,17 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
             hipLaunchKernelGGL(wgrad_reduce_partial_kernel, dim3((9 * 64 * 32 / 4 + 255) / 256, WGR_PARTS), dim3(256), 0, side,
                                (const float*)p.slab, nslab2, 9 * 64 * 32 / 4, part);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 32 + 255) / 256), dim3(256), 0, side, (const float*)part, WGR_PARTS, 32, 64,
-                               g->conv_w[1]);
+                               g->conv_w[1], unscale);
             }
         }
         if (two) SIR_HIP_TRY(hipEventRecord(h->bwd_ev[3], side));     // (the side stream's last launch)
         {
             SirProfScope prof(h, SIR_K_B_DGRAD2, st);
+            Wino2Geo geo2b;
+            if (wino2_geo(B, 32, d.wp1, 64, &geo2b) && (sir_wino2_mask() & 8) && (sir_f16_mask() & 16))
+                SIR_HIP_TRY((launch_conv_wino2<64, 32, 3, 0, 3, true>(st, &h->attr_wino2[10], (const float*)p.dz2, (const unsigned short*)p.wcb2t, (const float*)nullptr,
+                                                                    (const float*)nullptr, p.da1, B, 32, d.wp1, (float2*)nullptr, h->zero_page, h->num_cus)));
+            else
             hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<64, 32, 4, 2, 2, 0, 4>), dim3(d.c2gx, 1, B), dim3(256), conv_ns_lds_bytes(4, 2), st,
                                (const float*)p.dz2, (const unsigned short*)p.wcb2t, (const float*)nullptr, (const float*)nullptr, p.da1, 32, d.wp1,
                                16, d.wp2, (float2*)nullptr);
@@ -696,7 +749,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                            352, c1tmp);
         hipLaunchKernelGGL(colsum_kernel, dim3((352 + 63) / 64), dim3(256), 0, st, (const float*)c1tmp, 128, 352, 352, c1tot);
         hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(320), 0, st, (const float*)c1tot, (const double*)p.c1m,
-                           w->conv_w[0], scale, smean, sinv, (double)B * 64 * T, g->bn_w[0], g->bn_b[0], g->conv_w[0]);
+                           w->conv_w[0], scale, smean, sinv, (double)B * 64 * T, g->bn_w[0], g->bn_b[0], g->conv_w[0], unscale);
         KCHECK();
     }
     if (two) SIR_HIP_TRY(hipStreamWaitEvent(st, h->bwd_ev[3], 0));   // join: every gradient is final on the caller's stream

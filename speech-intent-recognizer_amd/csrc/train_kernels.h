@@ -315,7 +315,7 @@ __device__ __forceinline__ void head_bwd_utt(int b, const float* __restrict__ dl
                                              const float* __restrict__ y, const float* __restrict__ aw,
                                              const float* __restrict__ ab, float* __restrict__ dy,
                                              float* __restrict__ daw_part, float* __restrict__ dab_part,
-                                             int S, int C) {
+                                             int S, int C, float gscale) {
     __shared__ float dctx[512];
     __shared__ float sc[ATT_MAX_S], ds[ATT_MAX_S];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -377,7 +377,7 @@ __device__ __forceinline__ void head_bwd_utt(int b, const float* __restrict__ dl
         const float dc = dctx[c], ac = aw[c];
         float da = 0.0f;
         for (int t = 0; t < S; ++t) {
-            dy[((size_t)b * S + t) * 512 + c] = fmaf(sc[t], dc, ds[t] * ac);
+            dy[((size_t)b * S + t) * 512 + c] = gscale * fmaf(sc[t], dc, ds[t] * ac);     // (the backward's loss scale: a power of two, exact)
             da = fmaf(ds[t], yb[(size_t)t * 512 + c], da);
         }
         daw_part[(size_t)b * 512 + c] = da;
@@ -429,7 +429,7 @@ static __global__ __launch_bounds__(256) void head_colsum_kernel(const float* __
 // the array), columns [0, 768) -> direction 0, [768, 1536) -> direction 1
 static __global__ __launch_bounds__(256) void gru_bias_colsum_kernel(const float* __restrict__ bsum_i, const float* __restrict__ bsum_h, int rows,
                                                                       float* __restrict__ bi0, float* __restrict__ bi1,
-                                                                      float* __restrict__ bh0, float* __restrict__ bh1) {
+                                                                      float* __restrict__ bh0, float* __restrict__ bh1, float unscale) {
     __shared__ float red[4][64];
     const float* in = blockIdx.y ? bsum_h : bsum_i;
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;     // col < 1536 (grid.x = 24)
@@ -441,7 +441,7 @@ static __global__ __launch_bounds__(256) void gru_bias_colsum_kernel(const float
     if (part == 0) {
         const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         float* out = blockIdx.y ? (col < 768 ? bh0 : bh1) : (col < 768 ? bi0 : bi1);
-        out[col < 768 ? col : col - 768] = v;
+        out[col < 768 ? col : col - 768] = v * unscale;
     }
 }
 
@@ -491,20 +491,21 @@ __device__ __forceinline__ void fc_wgrad_block(int j, int half, const float* __r
 }
 
 // head backward, ONE launch for two independent jobs (both only need dlogits): workgroups [0, B) = one utterance each
-// (head_bwd_utt: fc + attention pooling backward, per-utterance attention partials); workgroups [B, B + 2 C) = the fc weight /
+// (head_bwd_utt: fc + attention pooling backward, per-utterance attention partials; its dy output -- and with it everything the
+// rest of the backward computes -- carries the loss scale `gscale`, see sir_bwd_loss_scale); workgroups [B, B + 2 C) = the fc weight /
 // bias gradients (fc_wgrad_block).  head_colsum_kernel adds the attention partials afterwards.
 static __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ fcw,
                                                               const float* __restrict__ y, const float* __restrict__ aw,
                                                               const float* __restrict__ ab, const float* __restrict__ ctx,
                                                               float* __restrict__ dy, float* __restrict__ daw_part,
                                                               float* __restrict__ dab_part, float* __restrict__ d_fc_w,
-                                                              float* __restrict__ d_fc_b, int B, int S, int C) {
+                                                              float* __restrict__ d_fc_b, int B, int S, int C, float gscale) {
     if ((int)blockIdx.x >= B) {
         const int i = blockIdx.x - B;
         fc_wgrad_block(i >> 1, i & 1, dlogits, ctx, d_fc_w, d_fc_b, B, C);
         return;
     }
-    head_bwd_utt(blockIdx.x, dlogits, fcw, y, aw, ab, dy, daw_part, dab_part, S, C);
+    head_bwd_utt(blockIdx.x, dlogits, fcw, y, aw, ab, dy, daw_part, dab_part, S, C, gscale);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -556,7 +557,7 @@ static __global__ __launch_bounds__(256) void train_prep_kernel(PrepJobs jobs) {
 
 // out_j[i] = sum_z slabs_j[z][i] for up to four jobs (blockIdx.y) with a common slab count; slab stride = n_j
 struct SlabJobs { const float* src[4]; float* out[4]; size_t n[4]; };
-static __global__ void slab_reduce_jobs_kernel(SlabJobs jobs, int nslab) {
+static __global__ void slab_reduce_jobs_kernel(SlabJobs jobs, int nslab, float unscale) {
     const int j = blockIdx.y;
     const size_t n = jobs.n[j];
     const float* __restrict__ s = jobs.src[j];
@@ -565,7 +566,7 @@ static __global__ void slab_reduce_jobs_kernel(SlabJobs jobs, int nslab) {
         float a = 0.0f;
 #pragma unroll 8
         for (int z = 0; z < nslab; ++z) a += s[(size_t)z * n + i];
-        o[i] = a;
+        o[i] = a * unscale;
     }
 }
 
@@ -727,7 +728,7 @@ static __global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_gru_kernel(
 // sums the (sum dy, sum dy*xhat) partials -> dbeta, dgamma and the two per-channel means used by dz
 static __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float2* __restrict__ part, int nblk, int C, double count,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               float* __restrict__ mdy, float* __restrict__ mdyx) {
+                                                               float* __restrict__ mdy, float* __restrict__ mdyx, float unscale) {
     __shared__ double rs[256], rq[256];
     const int c = blockIdx.x, tid = threadIdx.x;
     double s = 0.0, q = 0.0;
@@ -740,8 +741,8 @@ static __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float
         __syncthreads();
     }
     if (tid == 0) {
-        dbeta[c] = (float)rs[0];
-        dgamma[c] = (float)rq[0];
+        dbeta[c] = (float)rs[0] * unscale;              // parameter gradients leave the loss scale; the means below feed dz and keep it
+        dgamma[c] = (float)rq[0] * unscale;
         mdy[c] = (float)(rs[0] / count);
         mdyx[c] = (float)(rq[0] / count);
     }
@@ -925,7 +926,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
 static __global__ void conv1_bwd_finalize_kernel(const float* __restrict__ totals, const double* __restrict__ M, const float* __restrict__ w,
                                                  const float* __restrict__ scale, const float* __restrict__ mean,
                                                  const float* __restrict__ invstd, double count, float* __restrict__ dgamma,
-                                                 float* __restrict__ dbeta, float* __restrict__ dw) {
+                                                 float* __restrict__ dbeta, float* __restrict__ dw, float unscale) {
     const int idx = threadIdx.x;
     if (idx >= 288) return;
     const int c = idx / 9, tap = idx % 9;
@@ -934,8 +935,8 @@ static __global__ void conv1_bwd_finalize_kernel(const float* __restrict__ total
     double zx = 0.0;                                             // sum z * x_tap
     for (int t = 0; t < 9; ++t) zx += (double)w[c * 9 + t] * M[t <= tap ? c1_r_index(t, tap) : c1_r_index(tap, t)];
     const double xhx = (double)invstd[c] * (zx - (double)mean[c] * M[tap]);
-    dw[c * 9 + tap] = (float)((double)scale[c] * (A - m1 * M[tap] - m2 * xhx));
-    if (tap == 0) { dbeta[c] = (float)sdy; dgamma[c] = (float)sdx; }
+    dw[c * 9 + tap] = (float)((double)scale[c] * (A - m1 * M[tap] - m2 * xhx)) * unscale;
+    if (tap == 0) { dbeta[c] = (float)sdy * unscale; dgamma[c] = (float)sdx * unscale; }
 }
 
 // dW[co][ci][tap] = sum_blk slab[blk][tap][co][ci], in two ordered (deterministic) passes: WGR_PARTS partial sums over
@@ -962,7 +963,7 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_partial_kernel(const 
     }
     reinterpret_cast<float4*>(part)[(size_t)blockIdx.y * total4 + idx] = acc;
 }
-static __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nparts, int cin, int cout, float* __restrict__ dw) {
+static __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nparts, int cin, int cout, float* __restrict__ dw, float unscale) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // (tap, co, ci), ci fastest
     const int total = 9 * cout * cin;
     if (idx >= total) return;
@@ -970,7 +971,7 @@ static __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int n
     float s = 0.0f;
 #pragma unroll 8
     for (int k = 0; k < nparts; ++k) s += part[(size_t)k * total + idx];
-    dw[((size_t)co * cin + ci) * 9 + tap] = s;
+    dw[((size_t)co * cin + ci) * 9 + tap] = s * unscale;
 }
 
 // ------------------------------------------------------------------------------------------

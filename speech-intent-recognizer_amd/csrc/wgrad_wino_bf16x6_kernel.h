@@ -56,7 +56,12 @@ __device__ __forceinline__ float4 wgw_sub(const float4& x, const float4& y) { re
 __device__ __forceinline__ float4 wgw_neg(const float4& x) { return make_float4(-x.x, -x.y, -x.z, -x.w); }
 
 // dz: [B][H][W][COUT] (gradient of the raw conv output), a: [B][H][W][CIN] (the layer input), slab: [strips][4 i][4 j][COUT][CIN]
-template <int CIN, int COUT>
+// F16 (round 4): the products on the fp16 matrix cores (f16_split.h), as in gemm_tn2_bf16x6_kernel's F16 form: the transformed output
+// gradient P (it carries the backward's loss scale) as two planes (Ph, Pl'), the transformed input V scaled by 2^-5 (|V| <= 4 max |input|:
+// exact below |input| = 256, clamped beyond) as three (Vh, Vh 2^11, Vl'); Pl' Vh + Ph Vl' + Ph (Vh 2^11) into the one accumulator set,
+// 2^-11 x 2^5 in the epilogue.  The frequency stride of the LDS images stays three planes for both operands.
+constexpr int WGW_VS_LOG2 = -5;
+template <int CIN, int COUT, bool F16 = false>
 __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_wino_bf16x6_kernel(
     const float* __restrict__ dz, const float* __restrict__ a, float* __restrict__ slab, int B, int H, int W) {
     using C = WgwCfg<CIN, COUT>;
@@ -146,7 +151,17 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
         };
         auto put = [&](unsigned char* img, int plane, const float4& v) {           // img: the item's address in a frequency's first plane
             uint2 hh, mm, ll;
-            split3_quad(v, hh, mm, ll);
+            if constexpr (F16) {
+                if (plane == PPLANE) {                                               // P: two planes (gradient side)
+                    split2h_quad(v, hh, ll);
+                    *reinterpret_cast<uint2*>(img) = hh;
+                    *reinterpret_cast<uint2*>(img + plane) = ll;
+                    return;
+                }
+                tn2_split_b<WGW_VS_LOG2>(v, hh, mm, ll);                             // V: (Vh, Vh 2^11, Vl') of V / 32
+            } else {
+                split3_quad(v, hh, mm, ll);
+            }
             *reinterpret_cast<uint2*>(img) = hh;
             *reinterpret_cast<uint2*>(img + plane) = mm;
             *reinterpret_cast<uint2*>(img + 2 * plane) = ll;
@@ -244,22 +259,37 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
         const unsigned char* sb = wgl + ((s - 1) & 1) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < TPS / 16; ++ks) {
-            bf16x8 af[MTW][3], bf[NT][3];
+            constexpr int NPA = F16 ? 2 : 3;
+            bf16x8 af[MTW][NPA], bf[NT][3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
+                if (p < NPA) {
 #pragma unroll
-                for (int m = 0; m < MTW; ++m) af[m][p] = tn_tr_fragment<ZW>(sb + poff[m] + p * PPLANE + ks * 16 * ZW);
+                    for (int m = 0; m < MTW; ++m) af[m][p < NPA ? p : 0] = tn_tr_fragment<ZW>(sb + poff[m] + p * PPLANE + ks * 16 * ZW);
+                }
 #pragma unroll
                 for (int n = 0; n < NT; ++n) bf[n][p] = tn_tr_fragment<AW>(sb + voff[n] + p * VPLANE + ks * 16 * AW);
             }
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
+            if constexpr (F16) {
+                constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 2, 1};       // Pl' Vh, Ph Vl', Ph (Vh 2^11)
 #pragma unroll
-            for (int t6 = 0; t6 < 6; ++t6)
+                for (int t3 = 0; t3 < 3; ++t3)
 #pragma unroll
-                for (int m = 0; m < MTW; ++m)
+                    for (int m = 0; m < MTW; ++m)
 #pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][PA[t6]], bf[n][PB[t6]], acc[m][n], 0, 0, 0);
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[m][HA[t3]]), __builtin_bit_cast(f16x8, bf[n][HB[t3]]),
+                                                                              acc[m][n], 0, 0, 0);
+            } else {
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
+#pragma unroll
+                for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][PA[t6] % NPA], bf[n][PB[t6]], acc[m][n], 0, 0, 0);
+            }
         }
         tn2_barrier();
     }
@@ -272,7 +302,7 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = (mh * MTW + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp, ci = n * 32 + i32;
-                out[(size_t)co * CIN + ci] = acc[m][n][r];
+                out[(size_t)co * CIN + ci] = acc[m][n][r] * (F16 ? H3_LO_INV * (float)(1 << (-WGW_VS_LOG2)) : 1.0f);
             }
 }
 
@@ -298,7 +328,8 @@ static __global__ __launch_bounds__(256) void wgrad_wino_sum_kernel(const float*
 }
 
 // dw[co][ci][ky][kx] = (G^T dU G)[ky][kx],  dU: [4 i][4 j][co][ci];  G = (1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1)
-static __global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const float* __restrict__ du, int cin, int cout, float* __restrict__ dw) {
+static __global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const float* __restrict__ du, int cin, int cout, float* __restrict__ dw,
+                                                                       float unscale) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // (co, ci), ci fastest
     const int n = cout * cin;
     if (idx >= n) return;
@@ -317,8 +348,8 @@ static __global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const flo
     float* o = dw + (size_t)idx * 9;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-        o[ky * 3 + 0] = t[ky][0] + 0.5f * (t[ky][1] + t[ky][2]);
-        o[ky * 3 + 1] = 0.5f * (t[ky][1] - t[ky][2]);
-        o[ky * 3 + 2] = 0.5f * (t[ky][1] + t[ky][2]) + t[ky][3];
+        o[ky * 3 + 0] = (t[ky][0] + 0.5f * (t[ky][1] + t[ky][2])) * unscale;     // (the backward's loss scale leaves here: a power of two)
+        o[ky * 3 + 1] = (0.5f * (t[ky][1] - t[ky][2])) * unscale;
+        o[ky * 3 + 2] = (0.5f * (t[ky][1] + t[ky][2]) + t[ky][3]) * unscale;
     }
 }

@@ -60,6 +60,15 @@ def _views(m, bsz, t):
     return out
 
 
+def _loss_scale(bsz):
+    """The backward's internal loss scale (csrc/model_train.hip::sir_bwd_loss_scale): 2^8 x batch rounded up to a power of two.  The
+    intermediate gradients in the workspace carry it (the parameter gradients do not)."""
+    k = 8
+    while (1 << (k - 8)) < bsz and k < 24:
+        k += 1
+    return float(1 << k)
+
+
 def _rel(a, b):
     a, b = a.detach().cpu().double().flatten(), b.detach().cpu().double().flatten()
     rms = b.pow(2).mean().sqrt().item()
@@ -126,7 +135,7 @@ def test_train_forward_backward_stages(sd):
            "dx0": st["d_gru_in"], "da2": nhwc(st["d_conv2"]), "da1": nhwc(st["d_conv1"])}
     report = {}
     for k, r in {**fwd, **bwd}.items():
-        report[k] = _rel(v[k], r)[0]
+        report[k] = _rel(v[k] / _loss_scale(8) if k in bwd else v[k], r)[0]
     report["logits"] = _rel(logits, ref_logits)[0]
     print("train stage errors (max|a-b|/rms):", {k: f"{e:.1e}" for k, e in report.items()})
     gerr = {}
