@@ -105,7 +105,8 @@ __device__ long long w2_dbg_stamps[2][32];
 // F16 (round 4): the contraction on the fp16 matrix cores with the two-way split (f16_split.h) instead of bf16x6 -- the producers
 // write TWO planes (Vh, Vl' = residual * 2^11) instead of three (a third fewer split instructions and LDS writes), the consumers
 // issue THREE products per frequency and 16-deep step instead of six (Vl' Uh, Vh Ul', Vh (Uh 2^11): one accumulator, 2^11 too large,
-// scaled back in the epilogue; weights from prep_conv_w_wino_f16x3: same layout, three fp16 planes).  The part runs at its power
+// scaled back in the epilogue; weights from prep_conv_w_wino_f16x3: same layout, TWO fp16 planes (Uh, Ul') -- Uh 2^11 is formed in
+// registers, so the U stream that bounds the kernel is a third shorter as well).  The part runs at its power
 // cap: the matrix products ARE the energy.  Needs inputs inside fp16's range (activations: yes; gradients only under the loss
 // scale of the backward).  The V buffers keep their 48 KB stride (the row-transform exchange of the epilogue needs it).
 template <int CIN, int COUT, int OUT_MODE, int DBG = 0, int PRIO = 3, bool F16 = false>
@@ -289,10 +290,11 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
     // U fragment address = uniform part (plane, frequency, channel block, slice: scalar registers) + this lane's 32-bit byte offset
     const unsigned wlane = (unsigned)((m * 2 + h) * 16);
     const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(wpb) + (size_t)mn * 1024;
-    uint4 wq[4][3];                                                     // U fragments of the wave's four frequencies, one chunk ahead
-    auto load_w = [&](int gidx, int chh, uint4 (&q)[3]) {
+    constexpr int NPW = F16 ? 2 : 3;                                    // weight planes
+    uint4 wq[4][NPW];                                                   // U fragments of the wave's four frequencies, one chunk ahead
+    auto load_w = [&](int gidx, int chh, uint4 (&q)[NPW]) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NPW; ++p)
             q[p] = *reinterpret_cast<const uint4*>(wbase + ((size_t)(p * G + gidx) * (COUT * 2) + (size_t)chh * 128) * 16 + wlane);
     };
     int g0, ty0, ch, s_idx;
@@ -338,8 +340,15 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
 #pragma unroll
                     for (int p = 0; p < NPA; ++p)
                         a[jj][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(abase + p * W2_PLB + (2 * jp + jj) * 1024));
+                    if constexpr (F16) {                               // planes (Uh, Ul') -> fragments (Uh, Uh 2^11, Ul')
+                        const f16x8 uh = __builtin_bit_cast(f16x8, wq[2 * jp + jj][0]);
+                        bq[jj][0] = __builtin_bit_cast(bf16x8, uh);
+                        bq[jj][1] = __builtin_bit_cast(bf16x8, uh * (_Float16)2048.0f);
+                        bq[jj][2] = __builtin_bit_cast(bf16x8, wq[2 * jp + jj][1]);
+                    } else {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bq[jj][p] = __builtin_bit_cast(bf16x8, wq[2 * jp + jj][p]);
+                        for (int p = 0; p < 3; ++p) bq[jj][p] = __builtin_bit_cast(bf16x8, wq[2 * jp + jj][p < NPW ? p : 0]);
+                    }
                 }
                 if (DBG & 8) {
 #pragma unroll

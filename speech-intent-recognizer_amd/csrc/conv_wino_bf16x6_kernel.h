@@ -85,21 +85,20 @@ static __global__ void prep_conv_wT_wino_bf16x3_kernel(const float* __restrict__
 }
 
 // ---- f16x3 form of the same weights (second-generation kernel with F16 = true; f16_split.h) ------------------------------------
-// Three fp16 planes per value, same layout: plane 0 = Uh = fp16(U), plane 1 = Uh * 2^11, plane 2 = Ul' = fp16((U - Uh) * 2^11).
-// With the activations split into (Vh, Vl') the kernel accumulates Vl' Uh + Vh Ul' + Vh (Uh 2^11) = 2^11 V U into ONE accumulator
-// (three MFMAs, no second accumulator: the consumers' registers are full) and the epilogue scales by 2^-11.  Uh * 2^11 is exact
-// for |U| < 32; larger transformed weights are clamped and flagged in the handle's status word (bit 3: SIR_EINVAL at the next
-// sir_check_status) -- conv weights of this model are O(0.1).
-__device__ __forceinline__ void split_w_f16x3(float u, unsigned short& p0, unsigned short& p1, unsigned short& p2, unsigned int* status) {
+// TWO fp16 planes per value, same layout: plane 0 = Uh = fp16(U), plane 1 = Ul' = fp16((U - Uh) * 2^11).  With the activations
+// split into (Vh, Vl') the kernel accumulates Vl' Uh + Vh Ul' + Vh (Uh 2^11) = 2^11 V U into ONE accumulator (three MFMAs, no
+// second accumulator: the consumers' registers are full) and the epilogue scales by 2^-11; Uh 2^11 is formed in registers by the
+// consumer (four v_pk_mul_f16 per fragment: its VALU is idle, and the U stream is what bounds the kernel -- a third plane would be
+// a third more of it).  Uh * 2^11 is exact for |U| < 32; larger transformed weights are clamped and flagged in the handle's status
+// word (bit 3: SIR_EINVAL at the next sir_check_status) -- conv weights of this model are O(0.1).
+__device__ __forceinline__ void split_w_f16x3(float u, unsigned short& p0, unsigned short& p1, unsigned int* status) {
     constexpr float LIM = 31.984375f;                       // 65504 / 2048
     if (status && !(fabsf(u) <= LIM)) __hip_atomic_fetch_or(status, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u = __builtin_fminf(__builtin_fmaxf(u, -LIM), LIM);
     const _Float16 hi = (_Float16)u;
-    const _Float16 hi2 = (_Float16)((float)hi * H3_LO_SCALE);
     const _Float16 lo = (_Float16)((u - (float)hi) * H3_LO_SCALE);
     p0 = __builtin_bit_cast(unsigned short, hi);
-    p1 = __builtin_bit_cast(unsigned short, hi2);
-    p2 = __builtin_bit_cast(unsigned short, lo);
+    p1 = __builtin_bit_cast(unsigned short, lo);
 }
 __device__ __forceinline__ void prep_conv_w_wino_f16x3_elem(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin, int cout, int idx,
                                                             unsigned int* status) {
@@ -118,7 +117,7 @@ __device__ __forceinline__ void prep_conv_w_wino_f16x3_elem(const float* __restr
         u = fmaf(Gm[i][k], t, u);
     }
     if (j == 3) u = -u;
-    split_w_f16x3(u, wpb[idx], wpb[(size_t)total + idx], wpb[2 * (size_t)total + idx], status);
+    split_w_f16x3(u, wpb[idx], wpb[(size_t)total + idx], status);
 }
 static __global__ void prep_conv_w_wino_f16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin, int cout,
                                                      unsigned int* status) {
@@ -141,7 +140,7 @@ __device__ __forceinline__ void prep_conv_wT_wino_f16x3_elem(const float* __rest
         u = fmaf(Gm[i][k], t, u);
     }
     if (j == 3) u = -u;
-    split_w_f16x3(u, wpb[idx], wpb[(size_t)total + idx], wpb[2 * (size_t)total + idx], status);
+    split_w_f16x3(u, wpb[idx], wpb[(size_t)total + idx], status);
 }
 static __global__ void prep_conv_wT_wino_f16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpb, int cin_f, int cout_f,
                                                        unsigned int* status) {

@@ -28,28 +28,31 @@ constexpr size_t tn2_lds_bytes(bool a_km, int bm = TN2_BM) { return 2 * tn_lds_b
 
 // F16 (round 4): the products on the fp16 matrix cores with the two-way split of f16_split.h.  A (the gate gradients, which carry the
 // backward's loss scale and therefore sit in fp16's range) is staged as TWO planes (Ah, Al' = residual 2^11); B (activations / weights)
-// is first scaled by TN2_BS = 2^-4 (exact) and staged as THREE planes (Bh, Bh 2^11, Bl'), so that the three products
-// Al' Bh + Ah Bl' + Ah (Bh 2^11) = 2^11 A B go into ONE accumulator (the consumers' 64 accumulator registers are what the 128-register
-// budget of a 1024-thread workgroup allows) and the epilogue scales by 2^-11 / TN2_BS = 2^-7.  Bh 2^11 is exact while |B| TN2_BS < 32,
-// i.e. |B| < 512 (larger values are clamped: activations behind BatchNorm and weights are nowhere near).  3 instead of 6 MFMAs per
-// product, 5 instead of 6 planes through LDS, a shorter split.
+// is first scaled by TN2_BS = 2^-4 (exact) and staged as two planes as well (Bh, Bl'); the consumers form Bh 2^11 in registers (four
+// v_pk_mul_f16 per fragment), so that the three products Al' Bh + Ah Bl' + Ah (Bh 2^11) = 2^11 A B go into ONE accumulator (the
+// consumers' 64 accumulator registers are what the 128-register budget of a 1024-thread workgroup allows) and the epilogue scales by
+// 2^-11 / TN2_BS = 2^-7.  Bh 2^11 is exact while |B| TN2_BS < 32, i.e. |B| < 512 (larger values are clamped: activations behind
+// BatchNorm and weights are nowhere near).  3 instead of 6 MFMAs per product, 4 instead of 6 planes through LDS, a shorter split.
 constexpr float TN2_BS = 0.0625f;
 constexpr float TN2_BLIM = 31.984375f;                       // 65504 / 2048
-// (Bh, Bh 2^11, Bl') of v * SCALE (SCALE a power of two, |v| SCALE clamped below 32)
+// (Bh, Bl') of v * SCALE (SCALE a power of two; |v| SCALE clamped below 32 so that Bh 2^11 stays finite)
 template <int SCALE_LOG2 = -4>
-__device__ __forceinline__ void tn2_split_b(const float4& v, uint2& hh, uint2& h2, uint2& ll) {
+__device__ __forceinline__ void tn2_split_b(const float4& v, uint2& hh, uint2& ll) {
     constexpr float SC = SCALE_LOG2 >= 0 ? (float)(1 << (SCALE_LOG2 >= 0 ? SCALE_LOG2 : 0)) : 1.0f / (float)(1 << (SCALE_LOG2 < 0 ? -SCALE_LOG2 : 0));
-    auto pair = [](float a, float b, unsigned& h, unsigned& hs, unsigned& l) {
+    auto pair = [](float a, float b, unsigned& h, unsigned& l) {
         sir_f32x2 x = {__builtin_fminf(__builtin_fmaxf(a * SC, -TN2_BLIM), TN2_BLIM), __builtin_fminf(__builtin_fmaxf(b * SC, -TN2_BLIM), TN2_BLIM)};
         const sir_f16x2 hi = __builtin_convertvector(x, sir_f16x2);
         x -= __builtin_convertvector(hi, sir_f32x2);
         x *= H3_LO_SCALE;
         const sir_f16x2 lo = __builtin_convertvector(x, sir_f16x2);
-        const sir_f16x2 his = hi * (sir_f16x2){(_Float16)2048.0f, (_Float16)2048.0f};          // exact: |hi| < 32
-        h = __builtin_bit_cast(unsigned, hi); hs = __builtin_bit_cast(unsigned, his); l = __builtin_bit_cast(unsigned, lo);
+        h = __builtin_bit_cast(unsigned, hi); l = __builtin_bit_cast(unsigned, lo);
     };
-    pair(v.x, v.y, hh.x, h2.x, ll.x);
-    pair(v.z, v.w, hh.y, h2.y, ll.y);
+    pair(v.x, v.y, hh.x, ll.x);
+    pair(v.z, v.w, hh.y, ll.y);
+}
+// fragment of Bh -> fragment of Bh 2^11 (exact: |Bh| < 32)
+__device__ __forceinline__ bf16x8 tn2_hi2(const bf16x8& bh) {
+    return __builtin_bit_cast(bf16x8, __builtin_bit_cast(f16x8, bh) * (_Float16)2048.0f);
 }
 
 __device__ __forceinline__ void tn2_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -59,8 +62,8 @@ __global__ __launch_bounds__(TN2_THREADS, TN2_THREADS / 256) void gemm_tn2_bf16x
     constexpr int NC = BM >= 128 ? 2 : 1;                    // BM = 128: consumers 2 x 4, wave tile 64 x 64; BM = 64: 1 x 8, wave tile 64 x 32
     constexpr int AXW = BM * 2, BXW = TN_BN * 2;             // row bytes of the k-major images
     constexpr int APLANE = A_KM ? TN_BK * AXW : BM * TN_ROWB, BPLANE = TN_BK * BXW;
-    constexpr int NPA = F16 ? 2 : 3;                         // planes of A (B: three in both arithmetics)
-    constexpr int STAGE = NPA * APLANE + 3 * BPLANE;
+    constexpr int NPA = F16 ? 2 : 3, NPB = NPA;              // operand planes in LDS
+    constexpr int STAGE = NPA * APLANE + NPB * BPLANE;
     constexpr int NPT = 64 * TN2_NPW;                         // producer threads
     constexpr int NAQ = BM * 8 / NPT, NBQ = TN_BN * 8 / NPT;  // staging items per PRODUCER thread
     extern __shared__ __attribute__((aligned(16))) unsigned char tl2[];
@@ -176,13 +179,19 @@ __global__ __launch_bounds__(TN2_THREADS, TN2_THREADS / 256) void gemm_tn2_bf16x
 #pragma unroll
             for (int q = 0; q < NBQ; ++q) {
                 const int it = ptid + NPT * q;
-                uint2 hh, mm, ll;
-                if constexpr (F16) tn2_split_b(pb[q], hh, mm, ll);     // (Bh, Bh 2^11, Bl') of B / 16
-                else split3_quad(pb[q], hh, mm, ll);
                 unsigned char* d = BT + tn_kmaj_off<BXW>(it >> 6, 8 * (it & 63));
-                *reinterpret_cast<uint2*>(d) = hh;
-                *reinterpret_cast<uint2*>(d + BPLANE) = mm;
-                *reinterpret_cast<uint2*>(d + 2 * BPLANE) = ll;
+                if constexpr (F16) {
+                    uint2 hh, ll;
+                    tn2_split_b(pb[q], hh, ll);                        // (Bh, Bl') of B / 16
+                    *reinterpret_cast<uint2*>(d) = hh;
+                    *reinterpret_cast<uint2*>(d + BPLANE) = ll;
+                } else {
+                    uint2 hh, mm, ll;
+                    split3_quad(pb[q], hh, mm, ll);
+                    *reinterpret_cast<uint2*>(d) = hh;
+                    *reinterpret_cast<uint2*>(d + BPLANE) = mm;
+                    *reinterpret_cast<uint2*>(d + 2 * BPLANE) = ll;
+                }
             }
         };
         fetch(k_begin, pa0, pb0);
@@ -231,10 +240,14 @@ __global__ __launch_bounds__(TN2_THREADS, TN2_THREADS / 256) void gemm_tn2_bf16x
                         af[a][p < NPA ? p : 0] = A_KM ? tn_tr_fragment<AXW>(sb + aoff[a] + p * APLANE + ks * 16 * AXW)
                                                       : __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + aoff[a] + p * APLANE + ks * 32));
                 }
+                if (p < NPB) {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) bf[c][p] = tn_tr_fragment<BXW>(sb + boff[c] + p * BPLANE + ks * 16 * BXW);
+                    for (int c = 0; c < NC; ++c) bf[c][F16 && p == 1 ? 2 : p] = tn_tr_fragment<BXW>(sb + boff[c] + p * BPLANE + ks * 16 * BXW);
+                }
             }
             if constexpr (F16) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) bf[c][1] = tn2_hi2(bf[c][0]);
                 // af: 0 = Ah, 1 = Al'; bf: 0 = Bh, 1 = Bh 2^11, 2 = Bl' -- the two cross terms first, then the main one
                 constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 2, 1};
 #pragma unroll

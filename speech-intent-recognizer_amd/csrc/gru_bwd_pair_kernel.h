@@ -212,3 +212,184 @@ __global__ __launch_bounds__(GP_THREADS) void gru_bwd_pair_kernel(
         bh[u] = sum_r; bh[256 + u] = sum_z; bh[512 + u] = sum_nr;
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// Second layout of the same kernel (round 4): FOUR k per thread and EIGHT row parts.  The knock-outs of the two-k kernel
+// (profiles/r04/ab_bptt.txt) put the product loop at 57 of its 125 us, 45 of them the dgh broadcast reads from LDS: 96
+// ds_read_b128 per thread and step for 768 FMAs -- the loop is bound by LDS read issue, not by the FMAs.  Here thread
+// (k quad kq = 8 wave + lane / 8, row part rp = lane & 7) holds W[row][kq + 64 j], j = 0..3, for 48 of the 384 own rows: the same
+// 192 weights (30 float4 in registers, 18 in LDS) and 768 FMAs, but HALF the dgh reads (48 per thread and step).  The eight row
+// parts are summed with three DPP steps (quad xor 1, xor 2, row_half_mirror); lane rp then finishes utterance rp & 3 of the k
+// with j = 2 (half) + (rp >> 2) (own unit) and of the k with j = 2 (1 - half) + (rp >> 2) (the peer's): the granule and dhs layouts
+// [utterance][unit] are those of the two-k kernel.  dgh image: [utterance][8 parts][52] floats -- the parts 208 B apart sit on
+// eight disjoint 16-byte slots of the 256-byte bank line.
+// ------------------------------------------------------------------------------------------
+constexpr int GB4_RPS = 52, GB4_GS = 8 * GB4_RPS;          // floats per row part / per utterance
+constexpr int GB4_G = 12;                                   // groups of 4 own rows per row part (48 rows)
+constexpr int GB4_REGJ = 3;                                 // groups of k index 2 and 3 kept in registers (k index 0, 1: all 12) -> 30 float4
+constexpr int GB4_LDS4 = 2 * (GB4_G - GB4_REGJ);            // 18 float4 per thread in LDS
+constexpr size_t GB4_LDS_BYTES = ((size_t)GB4_LDS4 * GP_THREADS * 4 + GP_BW * GB4_GS + GP_BW * GP_UH) * 4;
+__device__ __forceinline__ float gp_half_mirror(float v) {   // lane i <-> lane 7 - i within each group of 8
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));
+}
+
+template <int KNOCK = 0>
+__global__ __launch_bounds__(GP_THREADS) void gru_bwd_pair_k4_kernel(
+    const float* __restrict__ dy, const float* __restrict__ gates, const float* __restrict__ y, const float* __restrict__ whh0,
+    const float* __restrict__ whh1, float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ bsum_i,
+    float* __restrict__ bsum_h, int B, int S, float* xbuf, unsigned int* status, unsigned epoch) {
+    extern __shared__ __attribute__((aligned(16))) float blds[];
+    gp_f4* wl4 = reinterpret_cast<gp_f4*>(blds);                          // [GB4_LDS4][threads] float4 (4 consecutive own rows)
+    float* gsh = blds + (size_t)GB4_LDS4 * GP_THREADS * 4;                // dgh of the own rows: [utterance][8][52]
+    float* dhs = gsh + GP_BW * GB4_GS;                                    // (W_hh^T dgh) of the own units: [utterance][128]
+    const int npairs_ = gridDim.x >> 1;
+    const int dir = blockIdx.y;
+    const int half = (npairs_ & 7) == 0 ? (blockIdx.x >> 3) & 1 : blockIdx.x & 1;
+    const int pair = (npairs_ & 7) == 0 ? (blockIdx.x & 7) + 8 * (blockIdx.x >> 4) : blockIdx.x >> 1;
+    const int b0 = pair * GP_BW;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* __restrict__ whh = dir ? whh1 : whh0;
+    unsigned long long* xg = reinterpret_cast<unsigned long long*>(xbuf) + (size_t)(pair * 2 + dir) * 2 * 2 * GP_BW * GP_UH;
+
+    // ---- matvec role ---------------------------------------------------------------------------------------
+    const int kq = (wv << 3) | (lane >> 3), rp = lane & 7;
+    gp_f4 wa[2][GB4_G], wb[2][GB4_REGJ];                                  // k index 0, 1: all groups; k index 2, 3: the first GB4_REGJ
+    {
+        auto grow = [&](int ro) { return (ro >> 7) * 256 + half * GP_UH + (ro & 127); };     // own row -> row of W_hh
+#pragma unroll
+        for (int i = 0; i < GB4_G; ++i) {
+            const int ro = rp * 48 + 4 * i;
+            const float* w0 = whh + (size_t)grow(ro) * 256, *w1 = whh + (size_t)grow(ro + 1) * 256;
+            const float* w2 = whh + (size_t)grow(ro + 2) * 256, *w3 = whh + (size_t)grow(ro + 3) * 256;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kq + 64 * j;
+                gp_f4 a;
+                a.x = w0[k]; a.y = w1[k]; a.z = w2[k]; a.w = w3[k];
+                if (j < 2) wa[j][i] = a;
+                else if (i < GB4_REGJ) wb[j - 2][i < GB4_REGJ ? i : 0] = a;
+                else wl4[(size_t)((j - 2) * (GB4_G - GB4_REGJ) + i - GB4_REGJ) * GP_THREADS + tid] = a;
+            }
+        }
+    }
+    // ---- gate role: unit ul = tid & 127 of this half, utterance bq = tid >> 7 ----------------------------
+    const int ul = tid & 127, bq = tid >> 7, u = half * GP_UH + ul;
+    const bool bvalid = (b0 + bq) < B;
+    int gslot[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { const int ro = 128 * g + ul; gslot[g] = bq * GB4_GS + (ro / 48) * GB4_RPS + ro % 48; }
+    for (int i = tid; i < GP_BW * GP_UH; i += GP_THREADS) dhs[i] = 0.0f;
+    float dhz = 0.0f;
+    float sum_r = 0.f, sum_z = 0.f, sum_n = 0.f, sum_nr = 0.f;
+    __syncthreads();
+
+    float in_r = 0.f, in_z = 0.f, in_n = 0.f, in_hn = 0.f, in_hp = 0.f, in_dy = 0.f;
+    auto fetch = [&](int it_) {
+        if (!bvalid || it_ >= S) return;
+        const int step_ = S - 1 - it_;
+        const int t_ = dir ? (S - 1 - step_) : step_;
+        const int tp_ = dir ? t_ + 1 : t_ - 1;
+        const size_t row_ = (size_t)(b0 + bq) * S + t_;
+        const float* gs = gates + (row_ * 2 + dir) * 1024;
+        in_r = gs[u]; in_z = gs[256 + u]; in_n = gs[512 + u]; in_hn = gs[768 + u];
+        in_hp = (step_ > 0) ? y[((size_t)(b0 + bq) * S + tp_) * 512 + dir * 256 + u] : 0.0f;
+        in_dy = dy[row_ * 512 + dir * 256 + u];
+    };
+    fetch(0);
+    const int fb = rp & 3, fj = rp >> 2;                       // this lane finishes utterance fb of k index 2 half + fj (own) / 2 (1 - half) + fj (peer)
+    const int kloc = kq + 64 * fj;                             // unit index inside a half
+    for (int it = 0; it < S; ++it) {
+        const int step = S - 1 - it;
+        const int t = dir ? (S - 1 - step) : step;
+        float drp = 0.f, dzp = 0.f, dnp = 0.f, dnr = 0.f, dhz_new = 0.f;
+        const float r = in_r, zg = in_z, nn = in_n, hn = in_hn, hprev = in_hp, dyv = in_dy;
+        fetch(it + 1);
+        if (bvalid) {
+            const size_t row = (size_t)(b0 + bq) * S + t;
+            const float dh = dyv + dhz + dhs[bq * GP_UH + ul];
+            const float dn = dh * (1.0f - zg);
+            const float dz = dh * (hprev - nn);
+            dnp = dn * (1.0f - nn * nn);
+            drp = dnp * hn * r * (1.0f - r);
+            dzp = dz * zg * (1.0f - zg);
+            dnr = dnp * r;
+            dhz_new = dh * zg;
+            float* gi_o = dgi + row * 1536 + dir * 768;
+            float* gh_o = dgh + row * 1536 + dir * 768;
+            gi_o[u] = drp; gi_o[256 + u] = dzp; gi_o[512 + u] = dnp;
+            gh_o[u] = drp; gh_o[256 + u] = dzp; gh_o[512 + u] = dnr;
+            sum_r += drp; sum_z += dzp; sum_n += dnp; sum_nr += dnr;
+        }
+        dhz = dhz_new;
+        gsh[gslot[0]] = drp; gsh[gslot[1]] = dzp; gsh[gslot[2]] = dnr;
+        __syncthreads();                                          // gsh complete; everyone has consumed dhs
+
+        float acc[4][GP_BW];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int bb = 0; bb < GP_BW; ++bb) acc[j][bb] = 0.0f;
+        const float* gpart = gsh + rp * GB4_RPS;
+        auto fma16 = [&](const gp_f4& w0, const gp_f4& w1, const gp_f4& w2, const gp_f4& w3, int i) {
+#pragma unroll
+            for (int bb = 0; bb < GP_BW; ++bb) {
+                gp_f4 g4;
+                if (KNOCK & 4) g4 = w0;
+                else g4 = *reinterpret_cast<const gp_f4*>(gpart + bb * GB4_GS + 4 * i);
+                const gp_f4* ws[4] = {&w0, &w1, &w2, &w3};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j][bb] = fmaf(ws[j]->x, g4.x, acc[j][bb]); acc[j][bb] = fmaf(ws[j]->y, g4.y, acc[j][bb]);
+                    acc[j][bb] = fmaf(ws[j]->z, g4.z, acc[j][bb]); acc[j][bb] = fmaf(ws[j]->w, g4.w, acc[j][bb]);
+                }
+            }
+        };
+        if (!(KNOCK & 2)) {
+#pragma unroll
+            for (int i = 0; i < GB4_REGJ; ++i) fma16(wa[0][i], wa[1][i], wb[0][i], wb[1][i], i);
+            asm volatile("" ::: "memory");                        // keep the LDS-resident weights in LDS
+#pragma unroll
+            for (int i = GB4_REGJ; i < GB4_G; ++i)
+                fma16(wa[0][i], wa[1][i], wl4[(size_t)(i - GB4_REGJ) * GP_THREADS + tid],
+                      wl4[(size_t)((GB4_G - GB4_REGJ) + i - GB4_REGJ) * GP_THREADS + tid], i);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int bb = 0; bb < GP_BW; ++bb) {                  // the eight row parts: lanes 8 m .. 8 m + 7
+                float v = acc[j][bb];
+                v += gp_quad_xor1(v); v += gp_quad_xor2(v); v += gp_half_mirror(v);
+                acc[j][bb] = v;
+            }
+        float s_lo = 0.0f, s_hi = 0.0f;                          // k index fj (units of half 0) / 2 + fj (units of half 1), utterance fb
+#pragma unroll
+        for (int bb = 0; bb < GP_BW; ++bb) {
+            const float lo_ = fj ? acc[1][bb] : acc[0][bb], hi_ = fj ? acc[3][bb] : acc[2][bb];
+            s_lo = (fb == bb) ? lo_ : s_lo;
+            s_hi = (fb == bb) ? hi_ : s_hi;
+        }
+        const float vown = half ? s_hi : s_lo, vpeer = half ? s_lo : s_hi;
+        const unsigned tagv = (epoch << 16) | (unsigned)(it + 1);
+        if (it + 1 < S) {
+            unsigned long long* gmine = xg + ((size_t)(it & 1) * 2 + half) * GP_BW * GP_UH;
+            const unsigned long long* gpeer = xg + ((size_t)(it & 1) * 2 + (half ^ 1)) * GP_BW * GP_UH;
+            unsigned long long pv = ((unsigned long long)tagv << 32) | __float_as_uint(vpeer);
+            if (!(KNOCK & 1)) {
+                __hip_atomic_store(gmine + fb * GP_UH + kloc, pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while ((unsigned)((pv = __hip_atomic_load(gpeer + fb * GP_UH + kloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tagv) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > GP_SPIN_LIMIT) { __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+            }
+            dhs[fb * GP_UH + kloc] = vown + __uint_as_float((unsigned)pv);
+        }
+        __syncthreads();                                          // dhs of the next step complete
+    }
+    if (bvalid) {
+        float* bi = bsum_i + (size_t)(b0 + bq) * 1536 + dir * 768;
+        float* bh = bsum_h + (size_t)(b0 + bq) * 1536 + dir * 768;
+        bi[u] = sum_r; bi[256 + u] = sum_z; bi[512 + u] = sum_n;
+        bh[u] = sum_r; bh[256 + u] = sum_z; bh[512 + u] = sum_nr;
+    }
+}

@@ -7,7 +7,8 @@
 int sir_launch_gru_bwd_pair(sir_handle* h, hipStream_t st, const float* dy, const float* gates, const float* y, const float* whh0,
                             const float* whh1, float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S) {
     // SIR_BPTT (A/B and timing knock-outs, devtools/gpu_ab_bptt.sh; default 0 = the product kernel): 1 = round 3's unpadded dgh image,
-    // 2 = product loop on v_pk_fma_f32, 3 = both; 16 + k = knock-out k of the product kernel (see the kernel's KNOCK comment)
+    // 2 = product loop on v_pk_fma_f32, 3 = both; 16 + k = knock-out k of the product kernel (see the kernel's KNOCK comment);
+    // 4 = the four-k / eight-row-part layout (gru_bwd_pair_k4_kernel), 36 + k its knock-outs
     static const int mode = getenv("SIR_BPTT") ? atoi(getenv("SIR_BPTT")) : 0;
     typedef void (*kern_t)(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, int, int, float*,
                            unsigned int*, unsigned);
@@ -21,10 +22,15 @@ int sir_launch_gru_bwd_pair(sir_handle* h, hipStream_t st, const float* dy, cons
         case 20: kern = gru_bwd_pair_kernel<4, true, false>; break;
         case 24: kern = gru_bwd_pair_kernel<8, true, false>; break;
         case 19: kern = gru_bwd_pair_kernel<3, true, false>; break;
+        case 4: kern = gru_bwd_pair_k4_kernel<0>; break;
+        case 37: kern = gru_bwd_pair_k4_kernel<1>; break;
+        case 38: kern = gru_bwd_pair_k4_kernel<2>; break;
+        case 40: kern = gru_bwd_pair_k4_kernel<4>; break;
         default: break;
     }
     if (!h->attr_gru_bwd) {
-        SIR_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GBP_LDS_BYTES));
+        static_assert(GB4_LDS_BYTES <= GBP_LDS_BYTES + 1024, "LDS of the two layouts");
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GB4_LDS_BYTES > GBP_LDS_BYTES ? GB4_LDS_BYTES : GBP_LDS_BYTES)));
         h->attr_gru_bwd = true;
     }
     const size_t npairs = (B + GP_BW - 1) / GP_BW;
@@ -33,7 +39,7 @@ int sir_launch_gru_bwd_pair(sir_handle* h, hipStream_t st, const float* dy, cons
     if (sir_xbuf_acquire(h, st, 2, npairs * 2 * 2 * 2 * GP_BW * GP_UH * 8, 0xFFFFu, &xbuf, &epoch) != SIR_OK) {
         return SIR_EHIP;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(npairs * 2), 2), dim3(GP_THREADS), GBP_LDS_BYTES, st, dy, gates, y, whh0, whh1, dgi,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(npairs * 2), 2), dim3(GP_THREADS), GB4_LDS_BYTES > GBP_LDS_BYTES ? GB4_LDS_BYTES : GBP_LDS_BYTES, st, dy, gates, y, whh0, whh1, dgi,
                        dgh, bsum_i, bsum_h, B, S, (float*)xbuf, h->status, epoch);
     SIR_HIP_TRY(hipGetLastError());
     return SIR_OK;

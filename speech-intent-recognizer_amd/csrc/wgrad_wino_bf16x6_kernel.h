@@ -58,8 +58,8 @@ __device__ __forceinline__ float4 wgw_neg(const float4& x) { return make_float4(
 // dz: [B][H][W][COUT] (gradient of the raw conv output), a: [B][H][W][CIN] (the layer input), slab: [strips][4 i][4 j][COUT][CIN]
 // F16 (round 4): the products on the fp16 matrix cores (f16_split.h), as in gemm_tn2_bf16x6_kernel's F16 form: the transformed output
 // gradient P (it carries the backward's loss scale) as two planes (Ph, Pl'), the transformed input V scaled by 2^-5 (|V| <= 4 max |input|:
-// exact below |input| = 256, clamped beyond) as three (Vh, Vh 2^11, Vl'); Pl' Vh + Ph Vl' + Ph (Vh 2^11) into the one accumulator set,
-// 2^-11 x 2^5 in the epilogue.  The frequency stride of the LDS images stays three planes for both operands.
+// exact below |input| = 256, clamped beyond) as two as well (Vh, Vl'; the consumers form Vh 2^11 in registers); Pl' Vh + Ph Vl' +
+// Ph (Vh 2^11) into the one accumulator set, 2^-11 x 2^5 in the epilogue.  The frequency stride of the LDS images stays three planes.
 constexpr int WGW_VS_LOG2 = -5;
 template <int CIN, int COUT, bool F16 = false>
 __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_wino_bf16x6_kernel(
@@ -152,13 +152,11 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
         auto put = [&](unsigned char* img, int plane, const float4& v) {           // img: the item's address in a frequency's first plane
             uint2 hh, mm, ll;
             if constexpr (F16) {
-                if (plane == PPLANE) {                                               // P: two planes (gradient side)
-                    split2h_quad(v, hh, ll);
-                    *reinterpret_cast<uint2*>(img) = hh;
-                    *reinterpret_cast<uint2*>(img + plane) = ll;
-                    return;
-                }
-                tn2_split_b<WGW_VS_LOG2>(v, hh, mm, ll);                             // V: (Vh, Vh 2^11, Vl') of V / 32
+                if (plane == PPLANE) split2h_quad(v, hh, ll);                        // P (gradient side): (Ph, Pl')
+                else tn2_split_b<WGW_VS_LOG2>(v, hh, ll);                            // V: (Vh, Vl') of V / 32
+                *reinterpret_cast<uint2*>(img) = hh;
+                *reinterpret_cast<uint2*>(img + plane) = ll;
+                return;
             } else {
                 split3_quad(v, hh, mm, ll);
             }
@@ -267,10 +265,14 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
 #pragma unroll
                     for (int m = 0; m < MTW; ++m) af[m][p < NPA ? p : 0] = tn_tr_fragment<ZW>(sb + poff[m] + p * PPLANE + ks * 16 * ZW);
                 }
+                if (p < NPA) {
 #pragma unroll
-                for (int n = 0; n < NT; ++n) bf[n][p] = tn_tr_fragment<AW>(sb + voff[n] + p * VPLANE + ks * 16 * AW);
+                    for (int n = 0; n < NT; ++n) bf[n][F16 && p == 1 ? 2 : p] = tn_tr_fragment<AW>(sb + voff[n] + p * VPLANE + ks * 16 * AW);
+                }
             }
             if constexpr (F16) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bf[n][1] = tn2_hi2(bf[n][0]);
                 constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 2, 1};       // Pl' Vh, Ph Vl', Ph (Vh 2^11)
 #pragma unroll
                 for (int t3 = 0; t3 < 3; ++t3)

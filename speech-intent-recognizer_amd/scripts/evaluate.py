@@ -33,10 +33,12 @@ def predict_loader(model, loader, device):
     model.eval()
     pipe = BatchPipeline(model, n_streams=2)          # consecutive batches alternate over two HIP streams
     preds, labels = [], []
+    from sir_amd.scripts.train import HostStager
+    stage = HostStager(device, slots=4)               # host batches: persistent pinned ring (see HostStager)
     for i, (mel, label) in enumerate(tqdm(loader, desc="Evaluating")):
         if mel is None or label is None or mel.size(0) == 0:
             continue                      # the reference would crash here (evaluate.py:81); skip instead
-        _, pred = pipe.infer(i, mel.to(device, non_blocking=True))
+        _, pred = pipe.infer(i, stage(mel))
         preds.append(pred)
         labels.append(label)
     if not preds:
@@ -65,7 +67,7 @@ def evaluate(args, config):
                                     use_cache=config.get("use_feature_cache", True),
                                     cache_dir=config.get("cache_dir", "data/cached_features"))
     test_loader = DataLoader(test_dataset, batch_size=config.get("batch_size", 32), shuffle=False,
-                             num_workers=config.get("num_workers", 4), collate_fn=collate_fn, pin_memory=True)
+                             num_workers=config.get("num_workers", 4), collate_fn=collate_fn, pin_memory=False)
     logger.info("Starting evaluation...")
     all_preds, all_labels = predict_loader(model, test_loader, device)
 

@@ -54,6 +54,38 @@ def _loss_fn(criterion):
     return criterion
 
 
+class HostStager:
+    """Host -> device hand-over of the batches a ``DataLoader`` yields, through a small ring of PERSISTENT pinned buffers.
+
+    ``mel.to(device, non_blocking=True)`` (train.py:86) on what the loader hands over is the slow link of the reference-shaped
+    route on this stack (devtools/dataloader_probe.py on MI355X / ROCm 7 / torch 2.10): a batch that sits in the workers'
+    shared memory copies at ~50 MB/s (``pin_memory=False``: 1 k utt/s), and with ``pin_memory=True`` torch's pinning thread
+    allocates a fresh pinned block per batch, which stalls for ~85 ms whenever the GPU is busy (3 k utt/s with ANY kernel in
+    flight, 112 k with an idle GPU).  Here a batch is copied by the CPU into one of ``slots`` pinned buffers allocated once
+    (13 MB memcpy), sent with an asynchronous copy on the caller's stream, and the buffer is reused after an event says that
+    copy is done.  Tensors already on the device pass through."""
+
+    def __init__(self, device, slots=3):
+        self.device, self.slots = device, slots
+        self.bufs, self.events, self.k = {}, {}, 0
+
+    def __call__(self, t):
+        if t.is_cuda:
+            return t
+        key = (tuple(t.shape), t.dtype)
+        if key not in self.bufs:
+            self.bufs[key] = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for _ in range(self.slots)]
+            self.events[key] = [torch.cuda.Event() for _ in range(self.slots)]
+        i = self.k % self.slots
+        self.k += 1
+        buf, ev = self.bufs[key][i], self.events[key][i]
+        ev.synchronize()                                   # (a never-recorded event returns at once)
+        buf.copy_(t)
+        out = buf.to(self.device, non_blocking=True)
+        ev.record()
+        return out
+
+
 def train_epoch(model, train_loader, optimizer, criterion, device, scaler=None):
     """One epoch (train.py:72-118); returns the mean of the per-step losses.  ``scaler`` is accepted
     for signature compatibility: the HIP path always computes in fp32 (the parity target is the fp32
@@ -62,6 +94,7 @@ def train_epoch(model, train_loader, optimizer, criterion, device, scaler=None):
     model.train()
     loss_fn = _loss_fn(criterion)
     losses = []
+    stage = HostStager(device)
     pbar = tqdm(train_loader, desc="Training", disable=_quiet())
     for batch_idx, (mel, label) in enumerate(pbar):
         if mel is None or label is None or mel.size(0) == 0:
@@ -72,8 +105,8 @@ def train_epoch(model, train_loader, optimizer, criterion, device, scaler=None):
                 train_ops.zero_contribution_step(model)
                 optimizer.step()
             continue
-        mel = mel.to(device, non_blocking=True)
-        label = label.to(device, non_blocking=True)
+        mel = stage(mel)                                   # host batches: persistent pinned ring (see HostStager)
+        label = stage(label)
         optimizer.zero_grad(set_to_none=True)
         output = model(mel)
         loss = loss_fn(output, label)
@@ -170,12 +203,13 @@ def validate(model, val_loader, criterion, device, scaler=None):
     losses = []
     correct = torch.zeros((), dtype=torch.int64, device=device)
     total = 0
+    stage = HostStager(device)
     with torch.no_grad():
         for mel, label in tqdm(val_loader, desc="Validating", disable=_quiet()):
             if mel is None or label is None or mel.size(0) == 0:
                 continue
-            mel = mel.to(device, non_blocking=True)
-            label = label.to(device, non_blocking=True)
+            mel = stage(mel)
+            label = stage(label)
             output, predicted = model.predict(mel)
             losses.append(loss_fn(output, label))
             correct += (predicted == label).sum()
@@ -244,10 +278,11 @@ def train(args, config):
     seed = int(config.get("seed", 0))
     train_sampler = train_ops.ShardSampler(len(train_dataset), rank, world, shuffle=True, seed=seed)
     val_sampler = train_ops.ShardSampler(len(val_dataset), rank, world, shuffle=False, pad=False)
+    # (pin_memory=False: train_epoch / validate stage host batches through their own persistent pinned ring, see HostStager)
     train_loader = None if (fused or hbm_cache) else DataLoader(train_dataset, batch_size=bs, sampler=train_sampler, num_workers=nw,
-                                                                collate_fn=collate_fn, pin_memory=True)
+                                                                collate_fn=collate_fn, pin_memory=False)
     val_loader = None if hbm_cache else DataLoader(val_dataset, batch_size=bs * 2, sampler=val_sampler, num_workers=nw,
-                                                   collate_fn=collate_fn, pin_memory=True)
+                                                   collate_fn=collate_fn, pin_memory=False)
 
     model = CNNAudioGRU(num_classes=config.get("num_labels", 31)).to(device)
     train_ops.broadcast_module_(model)             # identical initial weights / BN buffers on every rank
