@@ -69,10 +69,51 @@ def main():
             mel.to(dev, non_blocking=True)
             time.sleep(0.002)
 
-        consumers = [("none", consume_none), ("train_step", consume_train), ("gpu_kernel_only", consume_gpu_only),
+        # HostStager taken apart: where do the milliseconds of a staged step go?
+        stage_t = {"sync": 0.0, "cpu_copy": 0.0, "h2d_call": 0.0, "step": 0.0, "n": 0}
+        ring = [torch.empty(256, 64, 200).pin_memory() for _ in range(3)]
+        evs = [torch.cuda.Event() for _ in range(3)]
+        side = torch.cuda.Stream()
+
+        def make_staged(train, use_side):
+            def fn(mel, lab):
+                i = stage_t["n"] % 3
+                stage_t["n"] += 1
+                t0 = time.perf_counter()
+                evs[i].synchronize()
+                t1 = time.perf_counter()
+                if mel.shape == ring[i].shape:
+                    ring[i].copy_(mel)
+                    src = ring[i]
+                else:
+                    src = mel
+                t2 = time.perf_counter()
+                if use_side:
+                    with torch.cuda.stream(side):
+                        x = src.to(dev, non_blocking=True)
+                        evs[i].record()
+                    torch.cuda.current_stream().wait_stream(side)
+                else:
+                    x = src.to(dev, non_blocking=True)
+                    evs[i].record()
+                t3 = time.perf_counter()
+                if train:
+                    lab_d = lab.to(dev)
+                    opt.zero_grad(set_to_none=True)
+                    loss = train_ops.fused_cross_entropy(model(x), lab_d)
+                    loss.backward()
+                    opt.step()
+                t4 = time.perf_counter()
+                stage_t["sync"] += t1 - t0; stage_t["cpu_copy"] += t2 - t1; stage_t["h2d_call"] += t3 - t2; stage_t["step"] += t4 - t3
+            return fn
+
+        consumers = [("staged_only", make_staged(False, False)), ("staged_train", make_staged(True, False)),
+                     ("staged_train_side_stream", make_staged(True, True)),
+                     ("none", consume_none), ("train_step", consume_train), ("gpu_kernel_only", consume_gpu_only),
                      ("python_busy_2ms", consume_cpu_busy), ("sleep_2ms", consume_sleep)]
-        configs = [dict(num_workers=8, pin_memory=True), dict(num_workers=8, pin_memory=False), dict(num_workers=2, pin_memory=True),
-                   dict(num_workers=0, pin_memory=False)]
+        configs = [dict(num_workers=8, pin_memory=False), dict(num_workers=0, pin_memory=False), dict(num_workers=8, pin_memory=True)]
+        if len(sys.argv) > 2:
+            consumers = [c for c in consumers if c[0] in sys.argv[2].split(",")]
         for cfg in configs:
             for cname, fn in consumers:
                 loader = DataLoader(ds, batch_size=256, shuffle=True, collate_fn=tr.collate_fn, **cfg)
@@ -92,8 +133,13 @@ def main():
                     count += mel.size(0)
                 torch.cuda.synchronize()
                 el = time.perf_counter() - t0
-                print(json.dumps({"loader": cfg, "consumer": cname, "utts_per_s": round(count / el, 1), "epoch_s": round(el, 3),
-                                  "waiting_share": round(wait / el, 3)}), flush=True)
+                rec = {"loader": cfg, "consumer": cname, "utts_per_s": round(count / el, 1), "epoch_s": round(el, 3),
+                       "waiting_share": round(wait / el, 3)}
+                if cname.startswith("staged") and stage_t["n"]:
+                    rec["ms_per_batch"] = {k: round(v / stage_t["n"] * 1e3, 3) for k, v in stage_t.items() if k != "n"}
+                    for k in stage_t:
+                        stage_t[k] = 0 if k == "n" else 0.0
+                print(json.dumps(rec), flush=True)
                 del it, loader
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -51,6 +51,10 @@ constexpr int W2_PLB = 16 * 1024;                           // bytes per V plane
 constexpr int W2_V_BYTES = 3 * W2_PLB;                      // 49,152 per chunk; two buffers
 constexpr int W2_NRAW = 3;                                  // raw ring slots: a chunk's DMA pieces get two steps to land
 constexpr int W2_LDS_BYTES = 2 * W2_V_BYTES + W2_NRAW * W2_RAW_BYTES;   // 138,240
+// F16: two V planes per buffer (32 KB) + a DEDICATED 48 KB exchange area for the epilogue's row transform: 64 + 39 + 48 KB
+constexpr int W2_XCH_BYTES = 3 * W2_PLB;
+constexpr int w2_v_bytes(bool f16) { return f16 ? 2 * W2_PLB : W2_V_BYTES; }
+constexpr int w2_lds_bytes(bool f16) { return f16 ? 2 * 2 * W2_PLB + W2_NRAW * W2_RAW_BYTES + W2_XCH_BYTES : W2_LDS_BYTES; }   // 154,624 / 138,240
 constexpr int W2_THREADS = 768;                             // 4 producer waves + 8 consumer waves
 constexpr int W2_PPW = (W2_RAW_PIECES + 3) / 4;             // DMA pieces per wave of group B
 
@@ -108,16 +112,23 @@ __device__ long long w2_dbg_stamps[2][32];
 // scaled back in the epilogue; weights from prep_conv_w_wino_f16x3: same layout, TWO fp16 planes (Uh, Ul') -- Uh 2^11 is formed in
 // registers, so the U stream that bounds the kernel is a third shorter as well).  The part runs at its power
 // cap: the matrix products ARE the energy.  Needs inputs inside fp16's range (activations: yes; gradients only under the loss
-// scale of the backward).  The V buffers keep their 48 KB stride (the row-transform exchange of the epilogue needs it).
+// scale of the backward).  With 32 KB V buffers the LDS has room for a DEDICATED exchange area of the epilogue's row transform
+// (the bf16x6 form borrows the V buffer the task's last chunk just left and needs two extra barriers, A and B, around that, with
+// the producers parked at them): a consumer writes its pieces right behind its last MFMAs, the step's ONE barrier publishes them,
+// and the producers are transforming the next chunk meanwhile -- the epilogue was 26 of the f16x3 kernel's 109 us (knock-outs,
+// profiles/r04/bench_conv_wino2_f16x3.txt).
 template <int CIN, int COUT, int OUT_MODE, int DBG = 0, int PRIO = 3, bool F16 = false>
 __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpb, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, Wino2Geo geo, float2* __restrict__ stats, const float* __restrict__ zeros) {
     constexpr int NCH = CIN / 16, G = NCH * 16, NCHO = COUT >= 64 ? COUT / 64 : 1;
     static_assert(CIN % 16 == 0 && (COUT % 64 == 0 || COUT == 32), "16-channel chunks; 64-channel tasks (32: the n = 1 consumer waves only keep the barriers)");
+    static_assert(!F16 || NCH >= 2, "F16: a task's exchange pieces are read behind its closing barrier; the next task's are written >= one barrier later");
     extern __shared__ __attribute__((aligned(1024))) unsigned char w2s[];
-    unsigned char* const vbuf = w2s;                                    // [2][3 planes][16 f][1 KB]
-    unsigned char* const rawbuf = w2s + 2 * W2_V_BYTES;                 // [3][13 KB]
+    constexpr int VB = w2_v_bytes(F16);                                 // bytes per V buffer
+    unsigned char* const vbuf = w2s;                                    // [2][3 (F16: 2) planes][16 f][1 KB]
+    unsigned char* const rawbuf = w2s + 2 * VB;                         // [3][13 KB]
+    unsigned char* const xchbuf = rawbuf + W2_NRAW * W2_RAW_BYTES;      // F16 only: [8 waves][3 pieces][2 KB]
 
     // the wave index as a SCALAR (readfirstlane): everything derived from it -- roles, rows, channel slices, weight addresses -- then
     // lives in SGPRs; derived from threadIdx alone hipcc keeps it all in vector registers (+40 VGPRs in the consumer loop: spills)
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                     const int txx = (t0 + ttx) % TW;
                     z0 = txx == 0; z3 = txx == TW - 1;
                 }
-                const unsigned rb = raw_a + (s % W2_NRAW) * W2_RAW_BYTES, vd = v_a + (s & 1) * W2_V_BYTES;
+                const unsigned rb = raw_a + (s % W2_NRAW) * W2_RAW_BYTES, vd = v_a + (s & 1) * VB;
                 if (!(DBG & 4)) {
                 w2_f32x4 q[3][4];
 #pragma unroll
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             stamp();
-            if (s >= 1 && (s - 1) % NCH == NCH - 1) { w2_barrier(); w2_barrier(); }     // the consumers' row-transform exchange (barriers A, B)
+            if (!F16 && s >= 1 && (s - 1) % NCH == NCH - 1) { w2_barrier(); w2_barrier(); }     // bf16x6: the consumers' row-transform exchange (barriers A, B)
             w2_barrier();
         }
         return;
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
         w2_barrier();
         w2_barrier();
         for (int lt = 0; lt < ntask; ++lt)
-            for (int c = 0; c < NCH + 2; ++c) w2_barrier();
+            for (int c = 0; c < NCH + (F16 ? 0 : 2); ++c) w2_barrier();
         return;
     }
     // U fragment address = uniform part (plane, frequency, channel block, slice: scalar registers) + this lane's 32-bit byte offset
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
             stamp();
             const int sc = lt * NCH + c;
             const bool task_end = c == NCH - 1;
-            const unsigned char* abase = vbuf + (sc & 1) * W2_V_BYTES + h * 512 + m * 16 + (4 * mi) * 1024;
+            const unsigned char* abase = vbuf + (sc & 1) * VB + h * 512 + m * 16 + (4 * mi) * 1024;
             const int gnxt = (task_end ? 0 : c + 1) * 16 + 4 * mi;
             // two frequencies at a time (two independent accumulator chains in flight), each pair followed AT ONCE by the loads of ITS
             // weights for the next chunk, fenced: left to itself hipcc sinks all twelve weight loads to the end of the step and the next
@@ -380,13 +391,13 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
             if (!task_end) w2_barrier();
         }
         const int sc = lt * NCH + NCH - 1;                              // the task's last chunk: its V buffer becomes the exchange area
-        if (DBG & 16) { w2_barrier(); w2_barrier(); w2_barrier(); if (acc[0][0] == 1234.5f && acc[1][1] + acc[2][2] + acc[3][3] == 4.0f) out[0] = 1.0f; }
+        if (DBG & 16) { if (!F16) { w2_barrier(); w2_barrier(); } w2_barrier(); if (acc[0][0] == 1234.5f && acc[1][1] + acc[2][2] + acc[3][3] == 4.0f) out[0] = 1.0f; }
         else {
             {
-                w2_barrier();                                        // A: every consumer has read its last fragments of V[sc & 1]
+                if (!F16) w2_barrier();                              // A (bf16x6): every consumer has read its last fragments of V[sc & 1]
                 // column inverse transform (U_{i3} is stored negated); finisher k = row index of slice mn completes accumulator registers
                 // 4 k .. 4 k + 3 (tile column k, tile rows 4 h + e).  Piece (source i -> finisher k): W_i[b][4 k + e] as two float4 (b)
-                float4* const xch = reinterpret_cast<float4*>(vbuf + (sc & 1) * W2_V_BYTES);
+                float4* const xch = reinterpret_cast<float4*>(F16 ? xchbuf : vbuf + (sc & 1) * VB);
                 float own[2][4];
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {                          // one b at a time: 16 live registers instead of 32 beside the accumulators
@@ -402,7 +413,8 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                         }
                     }
                 }
-                w2_barrier();                                        // B: the pieces are in LDS
+                w2_barrier();                                        // B: the pieces are in LDS (F16: this IS the step's closing barrier -- the
+                                                                     // producers are already on the next chunk, nobody parks)
                 // Y[0][b] = (W0 + W1) + W2, Y[1][b] = (W1 - W2) - W3: always in THIS order, whichever row the finishing wave holds itself --
                 // the tile column a clip lands on depends on its position in the batch, and a clip's logits must not (bit for bit)
                 float Y[2][2][4];
@@ -423,8 +435,8 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                         }
                     }
                 }
-                w2_barrier();                                        // C (this step's closing barrier, early): the pieces are in registers, the producers
-                                                                     // may overwrite this V buffer -- they transform the next chunk while the outputs are finished here
+                if (!F16) w2_barrier();                              // C (bf16x6: this step's closing barrier, early): the pieces are in registers, the
+                                                                     // producers may overwrite this V buffer -- they transform the next chunk while the outputs are finished here
                 const int co = ch * 64 + mn * 32 + m;
                 float ssum = 0.0f, ssq = 0.0f;
                 float sc_ = 1.0f, sh_ = 0.0f;
@@ -513,11 +525,11 @@ static inline hipError_t launch_conv_wino2(hipStream_t st, bool* attr_done, cons
     Wino2Geo g;
     if (!wino2_geo(B, H, W, CIN > COUT ? CIN : COUT, &g)) return hipErrorInvalidValue;
     if (!*attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino2_bf16x6_kernel<CIN, COUT, OUT_MODE, DBG, PRIO, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino2_bf16x6_kernel<CIN, COUT, OUT_MODE, DBG, PRIO, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, w2_lds_bytes(F16));
         if (e != hipSuccess) return e;
         *attr_done = true;
     }
     const int nwg = g.NS < max_wg ? g.NS : max_wg;
-    hipLaunchKernelGGL((conv3x3_wino2_bf16x6_kernel<CIN, COUT, OUT_MODE, DBG, PRIO, F16>), dim3(nwg), dim3(W2_THREADS), W2_LDS_BYTES, st, x, wpb, scale, shift, out, g, stats, zeros);
+    hipLaunchKernelGGL((conv3x3_wino2_bf16x6_kernel<CIN, COUT, OUT_MODE, DBG, PRIO, F16>), dim3(nwg), dim3(W2_THREADS), w2_lds_bytes(F16), st, x, wpb, scale, shift, out, g, stats, zeros);
     return hipGetLastError();
 }
