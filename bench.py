@@ -47,8 +47,12 @@ NUM_CLASSES = 31
 N_POOL = 8                       # distinct batches staged in HBM (8 x 49 MB > the 256 MB MALL)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: bf16 MFMA, dense (no sparsity)
-# every contraction of the path computes its fp32 products as 6 bf16 MFMA products ("bf16x6",
-# csrc/bf16x6_kernels.h): the matrix pipe executes 6x the algorithmic FLOPs, so the peak for
+# Round 4: every contraction of the path computes its fp32 products as THREE fp16 MFMA products ("f16x3": two-way fp16 split of both
+# operands, csrc/f16_split.h / f16x3_kernels.h; rounds 1-3: six bf16 products, "bf16x6"): the matrix pipe executes 3x the
+# algorithmic FLOPs, so the peak for ALGORITHMIC fp32 FLOP/s is 2500/3 = 833.3 TFLOP/s.  (With bf16x6 it was 2500/6 = 416.7: a
+# fraction quoted against THAT peak in earlier rounds is twice the fraction of the same rate against this one.)
+PEAK_F16X3_TFLOPS = 2500.0 / 3.0
+# (rounds 1-3) six bf16 MFMA products per fp32 product: the matrix pipe executes 6x the algorithmic FLOPs, so the peak for
 # ALGORITHMIC fp32 FLOP/s on that path is 2500/6 TFLOP/s
 PEAK_BF16X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
@@ -71,7 +75,8 @@ FLOPS_PER_UTT = {
     "bwd_gru_dx_l1": _IH1, "bwd_gru_dx_l0": _IH0,
     "bwd_conv3_wgrad": _CONV3, "bwd_conv3_dgrad": _CONV3, "bwd_conv2_wgrad": _CONV2, "bwd_conv2_dgrad": _CONV2,
 }
-BF16X6_KERNELS = {k for k in FLOPS_PER_UTT if "conv1" not in k}
+BF16X6_KERNELS = {k for k in FLOPS_PER_UTT if "conv1" not in k}      # the matrix-core kernels (all on f16x3 since round 4; the name is historic)
+F16X3_KERNELS = BF16X6_KERNELS
 # csrc/conv_wino2_bf16x6_kernel.h (producer / consumer Winograd kernel; SIR_WINO2 selects the stages, default all three)
 WINOGRAD_KERNELS = {"conv2_mfma_bn_relu_pool", "conv3_mfma_bn_relu_pool", "train_conv2_fwd", "train_conv3_fwd", "bwd_conv3_dgrad",
                     "bwd_conv2_wgrad", "bwd_conv3_wgrad"}
@@ -79,8 +84,8 @@ WINOGRAD_KERNELS = {"conv2_mfma_bn_relu_pool", "conv3_mfma_bn_relu_pool", "train
 # largest single launch AND, as `by_symbol`, the symbol with the largest total time)
 KERNEL_SYMBOL = {
     "feat_frames": "feat_utt_kernel<float,false>", "conv1_bn_relu_pool": "conv1_mfma_bn_relu_pool_kernel",
-    "conv2_mfma_bn_relu_pool": "conv3x3_wino2_bf16x6_kernel<32,64,0>", "conv3_mfma_bn_relu_pool": "conv3x3_wino2_bf16x6_kernel<64,128,1>",
-    "gemm_ih_l0": "gemm_nt (input projections)", "gemm_ih_l1": "gemm_nt (input projections)",
+    "conv2_mfma_bn_relu_pool": "conv3x3_wino2_bf16x6_kernel<32,64,0,F16>", "conv3_mfma_bn_relu_pool": "conv3x3_wino2_bf16x6_kernel<64,128,1,F16>",
+    "gemm_ih_l0": "gemm_nt_f16x3_kernel", "gemm_ih_l1": "gemm_nt_f16x3_kernel",
     "gru_recurrence_l0": "gru_quad_kernel<false>", "gru_recurrence_l1": "gru_quad_kernel<false>",
     "attention_pool_fc_argmax": "attention_pool_kernel",
 }
@@ -186,25 +191,8 @@ def host_cpu_share(cap=16):
     """Threads the CPU leg may really use: min(affinity mask, cgroup CPU quota, cap).  The GPU box
     exposes every host core in the affinity mask but grants a share of them (16 per GPU); running
     hundreds of OpenMP threads against that quota would stall instead of measuring."""
-    n = os.cpu_count() or 1
-    try:
-        n = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            quota, period = f.read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                n = min(n, max(1, q // p))
-        except Exception:
-            pass
-    return max(1, min(n, cap, int(os.environ.get("SIR_BENCH_CPU_THREADS", cap))))
+    from sir_amd.dist_utils import host_cpu_share as share
+    return max(1, min(share(cap), int(os.environ.get("SIR_BENCH_CPU_THREADS", cap))))
 
 
 def host_cpu_info():
@@ -342,18 +330,19 @@ def mfma_roofline(kernel, avg_ms, launches, batch=BATCH):
     """roofline block of one matrix-core kernel from its average launch duration."""
     flops = FLOPS_PER_UTT[kernel] * batch
     achieved = flops / (avg_ms * 1e-3) / 1e12
-    x6 = kernel in BF16X6_KERNELS
-    peak = PEAK_BF16X6_TFLOPS if x6 else PEAK_F32_MFMA_TFLOPS
+    x6 = kernel in F16X3_KERNELS
+    peak = PEAK_F16X3_TFLOPS if x6 else PEAK_F32_MFMA_TFLOPS
     traffic, source = pmc_traffic(kernel)
     out = {"kernel": kernel, "bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": source,
            "avg_launch_ms": round(avg_ms, 5), "launches": launches, "flops_per_launch": flops,
-           "mfma_path": ("bf16x6: fp32 product = 6 bf16 MFMA products, f32 accumulate; peak = 2500/6 "
-                         "algorithmic TFLOP/s; executed bf16 MFMA rate = 6 x achieved") if x6 else "v_mfma_f32_32x32x2_f32",
+           "mfma_path": ("f16x3: fp32 product = 3 fp16 MFMA products (two-way fp16 split, residual scaled by 2^11), f32 accumulate; "
+                         "peak = 2500/3 algorithmic TFLOP/s; executed fp16 MFMA rate = 3 x achieved.  Rounds 1-3 ran bf16x6 "
+                         "(peak 2500/6): the same TFLOP/s was twice the fraction there") if x6 else "v_mfma_f32_32x32x2_f32",
            "fp32_mfma_peak": PEAK_F32_MFMA_TFLOPS}
     if kernel in WINOGRAD_KERNELS:
         out["algorithm"] = ("Winograd F(2x2,3x3): flops_per_launch counts the DIRECT convolution (the algorithmic work); the "
-                            "kernel executes 16/36 of its products, i.e. executed bf16 MFMA rate = 6 x 16/36 x achieved")
+                            "kernel executes 16/36 of its products, i.e. executed fp16 MFMA rate = 3 x 16/36 x achieved")
     return out
 
 
@@ -468,6 +457,8 @@ def dropin_epoch_leg(model, opt, fz, dev, step_rate, n_clips, batch=BATCH, worke
     from sir_amd.scripts.dataset import FSCIntentDataset
     from sir_amd.waveform_store import WaveformStore
     tmp = tempfile.mkdtemp(prefix="sir_dropin_")
+    from sir_amd.dist_utils import limit_host_threads
+    host_threads = limit_host_threads(reserve=workers)        # as train() does: torch's OpenMP pool inside the CPU quota
     try:
         t_frames = 1 + CLIP_LEN // 512
         pcm = torch.empty((n_clips, CLIP_LEN), dtype=torch.int16, device=dev)
@@ -513,6 +504,7 @@ def dropin_epoch_leg(model, opt, fz, dev, step_rate, n_clips, batch=BATCH, worke
             return best
 
         out = {"clips": n_clips, "batch": batch, "num_workers": workers, "augment_prob": aug_prob, "step_rate": step_rate,
+               "main_process_torch_threads": host_threads,
                "note": "fractions are of `train.value` (the bare step on HBM-resident clips); `steady_*` leaves out the time to the "
                        "first batch (DataLoader worker start-up, paid every epoch as in the reference: no persistent workers)"}
         # ---- route 1: the reference's own shape ----
@@ -843,8 +835,8 @@ def main():
                     "model_flops_per_utt_fwd_bwd": TRAIN_FLOPS_PER_UTT,
                     "roofline": dict(mfma_roofline(tdom, td_ms[tdom], td_cnt[tdom], batch),
                                      whole_step={"flops_per_step": TRAIN_FLOPS_PER_UTT * batch, "achieved": round(step_tf, 2),
-                                                 "peak": round(PEAK_BF16X6_TFLOPS, 1), "unit": "TFLOP/s",
-                                                 "frac": round(step_tf / PEAK_BF16X6_TFLOPS, 4),
+                                                 "peak": round(PEAK_F16X3_TFLOPS, 1), "unit": "TFLOP/s",
+                                                 "frac": round(step_tf / PEAK_F16X3_TFLOPS, 4),
                                                  "note": "1.2019 GFLOP/utt (fwd + dgrad + wgrad convention) x 256 / per-GPU step time"}),
                     "kernels_avg_ms": {k: round(v, 5) for k, v in tk_ms.items() if v > 0.0}}
             if rank == 0:
@@ -960,8 +952,8 @@ def main():
             tf = sym_flops[top] / (sym_ms[top] * 1e-3) / 1e12 if sym_flops[top] else None
             roofline["by_symbol"] = {"symbol": top, "total_ms_per_step": round(sym_ms[top], 5),
                                      "share_of_serial_step": round(sym_ms[top] / sum(sym_ms.values()), 4),
-                                     "achieved": round(tf, 3) if tf else None, "peak": round(PEAK_BF16X6_TFLOPS, 1), "unit": "TFLOP/s",
-                                     "frac": round(tf / PEAK_BF16X6_TFLOPS, 4) if tf else None,
+                                     "achieved": round(tf, 3) if tf else None, "peak": round(PEAK_F16X3_TFLOPS, 1), "unit": "TFLOP/s",
+                                     "frac": round(tf / PEAK_F16X3_TFLOPS, 4) if tf else None,
                                      "measured_in": "untimed HIP-event pass, one batch at a time (5 steps)"}
         feat_ms = kernel_ms.get("feat_frames", 0.0)      # ONE fused kernel since round 2 (profile id "feat_frames")
         gru = {}
@@ -983,8 +975,10 @@ def main():
                        "num_classes": NUM_CLASSES, "parallelism": f"utterance-sharded x{world}, no data-path collective",
                        "streams_per_gpu": ns, "pipelining": "library-owned (sir_pipeline): the caller uses one stream",
                        "share_gpu_rehearsal": share_gpu,
-                       "arithmetic": "fp32 accuracy end to end: contractions as bf16x6 (three-way bf16 split of both operands, six "
-                                     "v_mfma_f32_32x32x16_bf16 products, f32 accumulation), everything else fp32 VALU"},
+                       "arithmetic": "fp32 accuracy end to end: contractions as f16x3 (two-way fp16 split of both operands -- hi = fp16(x), lo = "
+                                     "fp16((x - hi) * 2^11) --, three v_mfma_f32_*_f16 products, f32 accumulation; error vs a float64 product "
+                                     "0.45-0.5x bf16x6's on the real GRU operands, profiles/r04/ab_f16x3.txt), the backward under a "
+                                     "power-of-two loss scale (exact), everything else fp32 VALU"},
             "dist": dist_info,
             "roofline": roofline,
             "kernels_avg_ms": {k: round(kernel_ms[k], 5) for k in infer_names if kernel_ms[k] > 0.0},

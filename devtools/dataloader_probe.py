@@ -24,6 +24,9 @@ def main():
     from sir_amd.scripts import train as tr
     from sir_amd.scripts.dataset import FSCIntentDataset
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    if os.environ.get("SIR_PROBE_LIMIT_THREADS", "1") == "1":
+        from sir_amd.dist_utils import limit_host_threads
+        print(json.dumps({"torch_threads_before": torch.get_num_threads(), "after": limit_host_threads(reserve=8)}), flush=True)
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     tmp = tempfile.mkdtemp(prefix="sir_probe_")

@@ -7,7 +7,8 @@ Reads   <dir>/infer_kernel_stats.csv, <dir>/train_kernel_stats.csv   (rocprofv3 
         <dir>/pmc/pmc_summary.csv                                    (rocprofv3 --pmc passes, devtools/gpu_pmc.sh + pmc_summary.py)
 and the algorithmic FLOP / byte table of bench.py (SURVEY.md section 8(d) per-utterance figures x 256), and prints for
 every kernel of the path: average duration, algorithmic TFLOP/s or TB/s, fraction of the peak that bounds it
-(bf16x6: 2500 / 6 = 416.7 TFLOP/s; f32 MFMA 157.3; HBM 8 TB/s -- MI355X_MICROARCH.md), matrix-pipe busy
+(round 4 on, f16x3: 2500 / 3 = 833.3 TFLOP/s; rounds 1-3, bf16x6: 2500 / 6 = 416.7; f32 MFMA 157.3; HBM 8 TB/s --
+MI355X_MICROARCH.md; the round is taken from the directory name), matrix-pipe busy
 (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)), LDS bank-conflict ratio (SQ_LDS_BANK_CONFLICT /
 SQ_LDS_IDX_ACTIVE), and HBM traffic (2 x FETCH_SIZE + WRITE_SIZE, KiB) over the algorithmic bytes.
 """
@@ -40,6 +41,7 @@ ROWS = [
     ("conv3x3_wino2_bf16x6_kernel<32, 64, 2", "train conv2 fwd (Winograd 2nd gen, raw out + BN partials)", "train", "mfma6", F["train_conv2_fwd"] * B, A1 + Z2),
     ("conv3x3_wino2_bf16x6_kernel<64, 128, 2", "train conv3 fwd (Winograd 2nd gen, raw out + BN partials)", "train", "mfma6", F["train_conv3_fwd"] * B, A2 + Z3),
     ("conv3x3_wino2_bf16x6_kernel<128, 64, 3", "bwd conv3 dgrad (Winograd 2nd gen)", "train", "mfma6", F["bwd_conv3_dgrad"] * B, Z3 + A2),
+    ("conv3x3_wino2_bf16x6_kernel<64, 32, 3", "bwd conv2 dgrad (Winograd 2nd gen)", "train", "mfma6", F["bwd_conv2_dgrad"] * B, Z2 + A1),
     ("conv3x3_wino_bf16x6_kernel<32, 64, 2", "train conv2 fwd (Winograd, raw out + BN partials)", "train", "mfma6", F["train_conv2_fwd"] * B, A1 + Z2),
     ("conv3x3_wino_bf16x6_kernel<64, 128, 2", "train conv3 fwd (Winograd, raw out + BN partials)", "train", "mfma6", F["train_conv3_fwd"] * B, A2 + Z3),
     ("conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 2", "train conv3 fwd (direct, raw out + BN partials)", "train", "mfma6", F["train_conv3_fwd"] * B, A2 + Z3),
@@ -52,6 +54,7 @@ ROWS = [
     ("conv_wgrad_bf16x6_kernel<32, 64>", "bwd conv2 wgrad", "train", "mfma6", F["bwd_conv2_wgrad"] * B, A1 + Z2),
     ("conv_wgrad_bf16x6_kernel<64, 128>", "bwd conv3 wgrad", "train", "mfma6", F["bwd_conv3_wgrad"] * B, A2 + Z3),
     ("gru_quad_kernel<true>", "train GRU recurrence (l0, l1)", "train", "mfma6", F["train_gru_l0"] * B, GI + Y + B * S * 2048 * 4),
+    ("gru_bwd_pair_k4_kernel", "BPTT recurrence, four-k layout (l1, l0)", "train", "mfma6", F["bwd_gru_l0"] * B, B * S * (2048 + 512 + 512 + 1536 + 1536) * 4),
     ("gru_bwd_pair_kernel", "BPTT recurrence (l1, l0)", "train", "mfma6", F["bwd_gru_l0"] * B, B * S * (2048 + 512 + 512 + 1536 + 1536) * 4),
     ("gru_bwd_quad_kernel", "BPTT recurrence, MFMA cluster (l1, l0)", "train", "mfma6", F["bwd_gru_l0"] * B, B * S * (2048 + 512 + 512 + 1536 + 1536) * 4),
     ("gemm_tn2_bf16x6_kernel<true", "GRU dW = dG^T X (l1, l0: mean)", "train", "mfma6", (F["bwd_gru_dw_l0"] + F["bwd_gru_dw_l1"]) * B // 2,
@@ -72,6 +75,8 @@ ROWS = [
     ("adam_multi_kernel", "Adam (multi-tensor)", "train", "hbm", None, 3261184 * 7 * 4),
     ("gemm_nt_bf16x6_v3_kernel", "input projections (l0, l1: mean)", "both", "mfma6", (F["gemm_ih_l0"] + F["gemm_ih_l1"]) * B // 2,
      (X0 + Y) * 3 // 4 + GI),
+    ("gemm_nt_f16x3_kernel", "input projections, f16x3 (l0, l1: mean)", "both", "mfma6", (F["gemm_ih_l0"] + F["gemm_ih_l1"]) * B // 2,
+     (X0 + Y) // 2 + GI),
     # ---- inference ----
     ("conv3x3_wino2_bf16x6_kernel<32, 64, 0", "conv2 + BN + ReLU + pool (Winograd 2nd gen)", "infer", "mfma6", F["conv2_mfma_bn_relu_pool"] * B, A1 + A2),
     ("conv3x3_wino2_bf16x6_kernel<64, 128, 1", "conv3 + BN + ReLU + pool (Winograd 2nd gen)", "infer", "mfma6", F["conv3_mfma_bn_relu_pool"] * B, A2 + X0 + X0 * 3 // 2),
@@ -86,7 +91,7 @@ ROWS = [
      (bench.GRU_ALGO_BYTES["gru_recurrence_l0"] + bench.GRU_ALGO_BYTES["gru_recurrence_l1"]) // 2),
     ("attention_pool_kernel", "attention pool + fc + argmax", "infer", "hbm", None, Y),
 ]
-PEAK = {"mfma6": bench.PEAK_BF16X6_TFLOPS, "mfma32": bench.PEAK_F32_MFMA_TFLOPS, "hbm": bench.PEAK_HBM_GBS / 1e3}
+PEAK = {"mfma6": bench.PEAK_BF16X6_TFLOPS, "mfma32": bench.PEAK_F32_MFMA_TFLOPS, "hbm": bench.PEAK_HBM_GBS / 1e3}      # "mfma6": set per round in main()
 SIMDS = 1024
 XCDS = 8              # rocprofv3 sums GRBM_GUI_ACTIVE over the eight XCDs: kernel cycles = value / 8
 
@@ -117,10 +122,16 @@ def first(d, pat):
 
 
 def main(d):
+    import re
+    m = re.search(r"r(\d+)$", os.path.basename(d.rstrip("/")))
+    f16x3 = bool(m) and int(m.group(1)) >= 4
+    PEAK["mfma6"] = bench.PEAK_F16X3_TFLOPS if f16x3 else bench.PEAK_BF16X6_TFLOPS
     stats = {"infer": read_stats(os.path.join(d, "infer_kernel_stats.csv")), "train": read_stats(os.path.join(d, "train_kernel_stats.csv"))}
     pmc = read_pmc(os.path.join(d, "pmc", "pmc_summary.csv"))
     print(f"# Roofline table, `{os.path.relpath(d, ROOT)}` (batch {B}, T = 200; generated by `python profiles/roofline_table.py {os.path.relpath(d, ROOT)}`)\n")
-    print("Peaks: bf16x6 contraction 416.7 TFLOP/s algorithmic (= 2500 / 6), HBM 8 TB/s.  `busy` = matrix-pipe busy cycles / "
+    print(("Peaks: f16x3 contraction 833.3 TFLOP/s algorithmic (= 2500 / 3 products per fp32 product; rounds 1-3 ran bf16x6 at 2500 / 6 = 416.7: "
+           "the same TFLOP/s was twice the fraction there)" if f16x3 else "Peaks: bf16x6 contraction 416.7 TFLOP/s algorithmic (= 2500 / 6)") +
+          ", HBM 8 TB/s.  `busy` = matrix-pipe busy cycles / "
           "(kernel cycles x 1024 SIMDs); `LDS confl` = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; `traffic` = 2 x FETCH_SIZE + "
           "WRITE_SIZE (KiB) per launch, `/algo` = over the algorithmic bytes of the launch.  A blank cell = counter not collected.\n")
     print("| kernel | leg | avg us | share of leg | algorithmic | frac of peak | MFMA busy | LDS confl | traffic MB | /algo |")

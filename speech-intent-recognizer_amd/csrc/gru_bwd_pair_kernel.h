@@ -214,21 +214,25 @@ __global__ __launch_bounds__(GP_THREADS) void gru_bwd_pair_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Second layout of the same kernel (round 4): FOUR k per thread and EIGHT row parts.  The knock-outs of the two-k kernel
+// Second layout of the same kernel (round 4): FOUR CONSECUTIVE k per thread and EIGHT row parts.  The knock-outs of the two-k kernel
 // (profiles/r04/ab_bptt.txt) put the product loop at 57 of its 125 us, 45 of them the dgh broadcast reads from LDS: 96
 // ds_read_b128 per thread and step for 768 FMAs -- the loop is bound by LDS read issue, not by the FMAs.  Here thread
-// (k quad kq = 8 wave + lane / 8, row part rp = lane & 7) holds W[row][kq + 64 j], j = 0..3, for 48 of the 384 own rows: the same
+// (k quad kq = 8 wave + lane / 8, row part rp = lane & 7) holds W[row][4 kq + j], j = 0..3, for 48 of the 384 own rows: the same
 // 192 weights (30 float4 in registers, 18 in LDS) and 768 FMAs, but HALF the dgh reads (48 per thread and step).  The eight row
-// parts are summed with three DPP steps (quad xor 1, xor 2, row_half_mirror); lane rp then finishes utterance rp & 3 of the k
-// with j = 2 (half) + (rp >> 2) (own unit) and of the k with j = 2 (1 - half) + (rp >> 2) (the peer's): the granule and dhs layouts
-// [utterance][unit] are those of the two-k kernel.  dgh image: [utterance][8 parts][52] floats -- the parts 208 B apart sit on
-// eight disjoint 16-byte slots of the 256-byte bank line.
+// parts are summed with three DPP steps (quad xor 1, xor 2, row_half_mirror).  A wave's 32 k are consecutive and lie in ONE half
+// of the hidden units (waves 0-3: units of half 0, waves 4-7: of half 1), which splits the exchange by wave: the four waves whose k
+// are the PEER's units only store granules, the four whose k are the own units only poll; lane rp finishes utterance rp & 3 of the
+// two k with j = 2 (rp >> 2) + {0, 1}, i.e. two neighbouring granules = one 16-byte write-through store / poll, and a wave
+// instruction covers four runs of 256 contiguous bytes (whole cache lines: a first four-k version with k = kq + 64 j touched
+// eight half lines per instruction and lost 19 us to the exchange).  dgh image: [utterance][8 parts][52] floats -- the parts 208 B
+// apart sit on eight disjoint 16-byte slots of the 256-byte bank line.
 // ------------------------------------------------------------------------------------------
 constexpr int GB4_RPS = 52, GB4_GS = 8 * GB4_RPS;          // floats per row part / per utterance
 constexpr int GB4_G = 12;                                   // groups of 4 own rows per row part (48 rows)
 constexpr int GB4_REGJ = 3;                                 // groups of k index 2 and 3 kept in registers (k index 0, 1: all 12) -> 30 float4
 constexpr int GB4_LDS4 = 2 * (GB4_G - GB4_REGJ);            // 18 float4 per thread in LDS
 constexpr size_t GB4_LDS_BYTES = ((size_t)GB4_LDS4 * GP_THREADS * 4 + GP_BW * GB4_GS + GP_BW * GP_UH) * 4;
+typedef unsigned int gb4_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float gp_half_mirror(float v) {   // lane i <-> lane 7 - i within each group of 8
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));
 }
@@ -252,23 +256,24 @@ __global__ __launch_bounds__(GP_THREADS) void gru_bwd_pair_k4_kernel(
     unsigned long long* xg = reinterpret_cast<unsigned long long*>(xbuf) + (size_t)(pair * 2 + dir) * 2 * 2 * GP_BW * GP_UH;
 
     // ---- matvec role ---------------------------------------------------------------------------------------
-    const int kq = (wv << 3) | (lane >> 3), rp = lane & 7;
+    const int kq = (wv << 3) | (lane >> 3), rp = lane & 7;                // k = 4 kq + j
     gp_f4 wa[2][GB4_G], wb[2][GB4_REGJ];                                  // k index 0, 1: all groups; k index 2, 3: the first GB4_REGJ
     {
         auto grow = [&](int ro) { return (ro >> 7) * 256 + half * GP_UH + (ro & 127); };     // own row -> row of W_hh
 #pragma unroll
         for (int i = 0; i < GB4_G; ++i) {
             const int ro = rp * 48 + 4 * i;
-            const float* w0 = whh + (size_t)grow(ro) * 256, *w1 = whh + (size_t)grow(ro + 1) * 256;
-            const float* w2 = whh + (size_t)grow(ro + 2) * 256, *w3 = whh + (size_t)grow(ro + 3) * 256;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = kq + 64 * j;
-                gp_f4 a;
-                a.x = w0[k]; a.y = w1[k]; a.z = w2[k]; a.w = w3[k];
-                if (j < 2) wa[j][i] = a;
-                else if (i < GB4_REGJ) wb[j - 2][i < GB4_REGJ ? i : 0] = a;
-                else wl4[(size_t)((j - 2) * (GB4_G - GB4_REGJ) + i - GB4_REGJ) * GP_THREADS + tid] = a;
+            const float4 r0 = *reinterpret_cast<const float4*>(whh + (size_t)grow(ro) * 256 + 4 * kq);
+            const float4 r1 = *reinterpret_cast<const float4*>(whh + (size_t)grow(ro + 1) * 256 + 4 * kq);
+            const float4 r2 = *reinterpret_cast<const float4*>(whh + (size_t)grow(ro + 2) * 256 + 4 * kq);
+            const float4 r3 = *reinterpret_cast<const float4*>(whh + (size_t)grow(ro + 3) * 256 + 4 * kq);
+            const gp_f4 c[4] = {{r0.x, r1.x, r2.x, r3.x}, {r0.y, r1.y, r2.y, r3.y}, {r0.z, r1.z, r2.z, r3.z}, {r0.w, r1.w, r2.w, r3.w}};
+            wa[0][i] = c[0];
+            wa[1][i] = c[1];
+            if (i < GB4_REGJ) { wb[0][i < GB4_REGJ ? i : 0] = c[2]; wb[1][i < GB4_REGJ ? i : 0] = c[3]; }
+            else {
+                wl4[(size_t)(i - GB4_REGJ) * GP_THREADS + tid] = c[2];
+                wl4[(size_t)((GB4_G - GB4_REGJ) + i - GB4_REGJ) * GP_THREADS + tid] = c[3];
             }
         }
     }
@@ -296,8 +301,9 @@ __global__ __launch_bounds__(GP_THREADS) void gru_bwd_pair_k4_kernel(
         in_dy = dy[row_ * 512 + dir * 256 + u];
     };
     fetch(0);
-    const int fb = rp & 3, fj = rp >> 2;                       // this lane finishes utterance fb of k index 2 half + fj (own) / 2 (1 - half) + fj (peer)
-    const int kloc = kq + 64 * fj;                             // unit index inside a half
+    const int fb = rp & 3, fj = rp >> 2;                       // this lane finishes utterance fb of k index 2 fj and 2 fj + 1
+    const bool own_wave = (wv >> 2) == half;                   // the wave's 32 k are this half's own units (else the peer's)
+    const int kl = (4 * kq + 2 * fj) & 127;                    // unit index (inside its half) of the first of the lane's two k
     for (int it = 0; it < S; ++it) {
         const int step = S - 1 - it;
         const int t = dir ? (S - 1 - step) : step;
@@ -353,36 +359,43 @@ __global__ __launch_bounds__(GP_THREADS) void gru_bwd_pair_k4_kernel(
                 fma16(wa[0][i], wa[1][i], wl4[(size_t)(i - GB4_REGJ) * GP_THREADS + tid],
                       wl4[(size_t)((GB4_G - GB4_REGJ) + i - GB4_REGJ) * GP_THREADS + tid], i);
         }
+        // this lane's two values: k index 2 fj, 2 fj + 1 of utterance fb, summed over the eight row parts (lanes 8 m .. 8 m + 7)
+        float v0 = 0.0f, v1 = 0.0f;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int bb = 0; bb < GP_BW; ++bb) {                  // the eight row parts: lanes 8 m .. 8 m + 7
+            for (int bb = 0; bb < GP_BW; ++bb) {
                 float v = acc[j][bb];
                 v += gp_quad_xor1(v); v += gp_quad_xor2(v); v += gp_half_mirror(v);
-                acc[j][bb] = v;
+                if ((j & 1) == 0) v0 = (fb == bb && fj == (j >> 1)) ? v : v0;
+                else v1 = (fb == bb && fj == (j >> 1)) ? v : v1;
             }
-        float s_lo = 0.0f, s_hi = 0.0f;                          // k index fj (units of half 0) / 2 + fj (units of half 1), utterance fb
-#pragma unroll
-        for (int bb = 0; bb < GP_BW; ++bb) {
-            const float lo_ = fj ? acc[1][bb] : acc[0][bb], hi_ = fj ? acc[3][bb] : acc[2][bb];
-            s_lo = (fb == bb) ? lo_ : s_lo;
-            s_hi = (fb == bb) ? hi_ : s_hi;
-        }
-        const float vown = half ? s_hi : s_lo, vpeer = half ? s_lo : s_hi;
         const unsigned tagv = (epoch << 16) | (unsigned)(it + 1);
         if (it + 1 < S) {
-            unsigned long long* gmine = xg + ((size_t)(it & 1) * 2 + half) * GP_BW * GP_UH;
-            const unsigned long long* gpeer = xg + ((size_t)(it & 1) * 2 + (half ^ 1)) * GP_BW * GP_UH;
-            unsigned long long pv = ((unsigned long long)tagv << 32) | __float_as_uint(vpeer);
-            if (!(KNOCK & 1)) {
-                __hip_atomic_store(gmine + fb * GP_UH + kloc, pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned spins = 0;
-                while ((unsigned)((pv = __hip_atomic_load(gpeer + fb * GP_UH + kloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tagv) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > GP_SPIN_LIMIT) { __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            // [parity][writer half][utterance][unit of the READER's half] granules {value, tag}; the lane's two are neighbours
+            unsigned long long* gmine = xg + ((size_t)(it & 1) * 2 + half) * GP_BW * GP_UH + fb * GP_UH + kl;
+            const unsigned long long* gpeer = xg + ((size_t)(it & 1) * 2 + (half ^ 1)) * GP_BW * GP_UH + fb * GP_UH + kl;
+            if (!own_wave) {                                      // the peer's units: publish the partials, nothing to wait for
+                if (!(KNOCK & 1)) {
+                    const gb4_u32x4 g2 = {__float_as_uint(v0), tagv, __float_as_uint(v1), tagv};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(gmine), "v"(g2) : "memory");
                 }
+            } else {                                              // own units: complete them with the peer's partials
+                float p0 = 0.0f, p1 = 0.0f;
+                if (!(KNOCK & 1)) {
+                    unsigned spins = 0;
+                    for (;;) {
+                        gb4_u32x4 g2;
+                        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g2) : "v"(gpeer) : "memory");
+                        p0 = __uint_as_float(g2.x); p1 = __uint_as_float(g2.z);
+                        if (g2.y == tagv && g2.w == tagv) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > GP_SPIN_LIMIT) { __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    }
+                }
+                dhs[fb * GP_UH + kl] = v0 + p0;                   // (dhs was last read before the barrier above)
+                dhs[fb * GP_UH + kl + 1] = v1 + p1;
             }
-            dhs[fb * GP_UH + kloc] = vown + __uint_as_float((unsigned)pv);
         }
         __syncthreads();                                          // dhs of the next step complete
     }

@@ -19,7 +19,9 @@ int sir_launch_gru_quad(sir_handle* h, hipStream_t st, bool save, const float* g
     }
     const dim3 grid(4 * (unsigned)clusters);
     // SIR_GRU_DBG: timing knock-outs and fault injection of gru_quad_kernel (see its `dbg` comment); 0 in production
-    static const int dbg = getenv("SIR_GRU_DBG") ? atoi(getenv("SIR_GRU_DBG")) : 0;
+    static const int dbg0 = getenv("SIR_GRU_DBG") ? atoi(getenv("SIR_GRU_DBG")) : 0;
+    static const int delay = getenv("SIR_GQ_DELAY") ? atoi(getenv("SIR_GQ_DELAY")) & 31 : GQ_POLL_DELAY;      // A/B of the first poll's delay
+    const int dbg = (dbg0 & ~(31 << 8)) | ((((dbg0 >> 8) & 31) ? ((dbg0 >> 8) & 31) : delay) << 8);
     if (save)
         hipLaunchKernelGGL(gru_quad_kernel<true>, grid, dim3(GQ_THREADS), GQ_LDS_BYTES, st, gi, whh0, whh1, bhh0, bhh1, y, B, S, gates,
                            (unsigned long long*)xbuf, h->status, dbg, epoch, yplanes, (const uint4*)wfrag0, (const uint4*)wfrag1);

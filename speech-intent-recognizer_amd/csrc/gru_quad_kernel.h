@@ -35,7 +35,7 @@ constexpr int GQ_NPL = 2;                 // h planes: hi, scaled residual
 constexpr int GQ_BUFB = GQ_NPL * GQ_PLANEB;    // one parity buffer: 16,896 B
 constexpr size_t GQ_LDS_BYTES = 2 * (size_t)GQ_BUFB;
 constexpr unsigned GQ_SPIN_LIMIT = 1u << 22;
-constexpr int GQ_POLL_DELAY = 16;          // x 64 cycles between the granule stores and the first poll round (see the poll loop)
+constexpr int GQ_POLL_DELAY = 16;          // default, x 64 cycles between the granule stores and the first poll round (see the poll loop); passed in dbg bits 8-12
 constexpr size_t GQ_XBUF_PER_CLUSTER = (size_t)2 * 4 * GQ_NU * GQ_UQ * 8;   // [parity][quarter][wave][store 0 | 1][lane][2] granules (producer-thread order)
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     // dbg (timing experiments only, results invalid): bit 0 = do not wait for the granules, bit 1 = skip the MFMAs,
     // bit 2 = skip publish + receive; fault injection for the status-word test: bit 3 = quarter 3 never publishes (its
     // peers time out), bit 4 = spin limit 4096 instead of 2^22 (so that the injected timeout takes milliseconds);
-    // bits 8-12 = extra delay of the first poll round in units of 64 cycles (results stay valid)
+    // bits 8-12 = delay of the first poll round in units of 64 cycles (the launcher passes GQ_POLL_DELAY or SIR_GQ_DELAY; results stay valid)
     extern __shared__ __attribute__((aligned(16))) unsigned char qlds[];
     // blockIdx.x = L -> (quarter, cluster).  Workgroup L runs on XCD L % 8 (round-robin dispatch): with the clusters in eights the four
     // quarters of a cluster are L = x, x + 8, x + 16, x + 24 of a block of 32 -- one XCD, so that the per-step exchange stays inside
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
             // comes back stale after ~0.7 us and the round that succeeds starts only then; a first round that leaves ~0.45 us
             // later is the one that succeeds (measured per layer launch: 106 us with no delay, 102.4 at 8 x 64 cycles,
             // 100.4 at 16, 102 at 20, 107 at 24).  dbg bits 8-12 add to the delay (experiments).
-            for (int i = 0; i < GQ_POLL_DELAY + ((dbg >> 8) & 31); ++i) __builtin_amdgcn_s_sleep(1);
+            for (int i = 0; i < ((dbg >> 8) & 31); ++i) __builtin_amdgcn_s_sleep(1);
             for (;;) {
                 {
                     // six 16-byte loads (sc1: past the non-coherent caches, like the relaxed agent-scope atomic loads they replace),

@@ -12,6 +12,43 @@ import torch.distributed as dist
 from torch.utils.data import Sampler
 
 
+def host_cpu_share(cap=None):
+    """CPUs this process may really use: min(affinity mask, cgroup CPU quota[, cap])."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, min(n, cap) if cap else n)
+
+
+def limit_host_threads(reserve=0):
+    """Cap torch's intra-op (OpenMP) thread pool at the CPUs the cgroup grants.  A GPU box shows every host core (256) but grants a
+    share of them (16 per GPU): with the default pool every CPU-side tensor op of the main process (a 13 MB batch copy, a stack)
+    wakes 256 spinning threads, the cgroup throttles the whole process tree, and the kernel-launching thread crawls (measured:
+    61 ms per training step instead of 1.3 with DataLoader workers beside it, profiles/r04/dataloader_probe.txt).  The reference's
+    orchestrator exports OMP_NUM_THREADS=1 for the same reason (run_pipeline.py:42); an explicit OMP_NUM_THREADS is respected."""
+    if os.environ.get("OMP_NUM_THREADS"):
+        return torch.get_num_threads()
+    n = max(1, host_cpu_share() - reserve)
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+    return torch.get_num_threads()
+
+
 def env_rank():
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
             int(os.environ.get("LOCAL_RANK", "0")))

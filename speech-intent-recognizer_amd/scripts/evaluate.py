@@ -51,6 +51,8 @@ def predict_loader(model, loader, device):
 
 def evaluate(args, config):
     _native.require_hip()
+    from sir_amd.dist_utils import limit_host_threads
+    limit_host_threads(reserve=int(config.get("num_workers", 4)))
     device = torch.device("cuda", torch.cuda.current_device())
     logger.info(f"Using device: {device}")
     with open(args.label_map, "r") as f:

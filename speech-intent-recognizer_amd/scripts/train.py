@@ -235,6 +235,7 @@ def train(args, config):
     from sir_amd.scripts.dataset import FSCIntentDataset
 
     _native.require_hip()
+    train_ops.limit_host_threads(reserve=int(config.get("num_workers", 2)))     # (the DataLoader workers get their share of the CPU quota)
     rank, world, local_rank = train_ops.init_distributed()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)

@@ -15,7 +15,7 @@ import torch
 
 from . import _native, ops
 from .dist_utils import (ShardSampler, all_reduce_mean_, all_reduce_sum_, broadcast_module_,  # noqa: F401
-                         init_distributed, shutdown_distributed, world_size)
+                         init_distributed, limit_host_threads, shutdown_distributed, world_size)
 from .featurizer import get_featurizer
 
 _seed_counter = itertools.count(1)
