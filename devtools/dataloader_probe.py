@@ -115,6 +115,9 @@ def main():
                      ("none", consume_none), ("train_step", consume_train), ("gpu_kernel_only", consume_gpu_only),
                      ("python_busy_2ms", consume_cpu_busy), ("sleep_2ms", consume_sleep)]
         configs = [dict(num_workers=8, pin_memory=False), dict(num_workers=0, pin_memory=False), dict(num_workers=8, pin_memory=True)]
+        if os.environ.get("SIR_PROBE_SPAWN", "0") == "1":     # workers that do NOT inherit the parent's HIP / KFD state (fresh interpreters)
+            configs = [dict(num_workers=8, pin_memory=False, multiprocessing_context="spawn"),
+                       dict(num_workers=8, pin_memory=False, multiprocessing_context="forkserver")]
         if len(sys.argv) > 2:
             consumers = [c for c in consumers if c[0] in sys.argv[2].split(",")]
         for cfg in configs:

@@ -17,6 +17,6 @@ cd /tmp && export TMPDIR=/tmp
 # inference leg alone, strictly serial (one stream) so that per-kernel averages are the kernels' own durations
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o infer -- python3 $R/bench.py --steps 30 --warmup 5 --repeats 1 --no-cpu-baseline --no-train --sustain-seconds 0 --streams 1 > $R/gpurun_out/prof.log 2>&1 || { tail -20 $R/gpurun_out/prof.log; exit 1; }
 # training legs (plain + augmented) with a short inference part
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o train -- python3 $R/bench.py --steps 2 --warmup 1 --repeats 1 --train-steps 30 --no-cpu-baseline --no-dist-leg --sustain-seconds 0 --streams 1 > $R/gpurun_out/prof_train.log 2>&1 || { tail -20 $R/gpurun_out/prof_train.log; exit 1; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o train -- python3 $R/bench.py --steps 2 --warmup 1 --repeats 1 --train-steps 30 --no-cpu-baseline --no-dist-leg --no-dropin --sustain-seconds 0 --streams 1 > $R/gpurun_out/prof_train.log 2>&1 || { tail -20 $R/gpurun_out/prof_train.log; exit 1; }
 ls -R $R/gpurun_out/prof | head -20
 fi

@@ -6,14 +6,15 @@
 
 int sir_launch_gru_bwd_pair(sir_handle* h, hipStream_t st, const float* dy, const float* gates, const float* y, const float* whh0,
                             const float* whh1, float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S) {
-    // SIR_BPTT (A/B and timing knock-outs, devtools/gpu_ab_bptt.sh; default 0 = the product kernel): 1 = round 3's unpadded dgh image,
-    // 2 = product loop on v_pk_fma_f32, 3 = both; 16 + k = knock-out k of the product kernel (see the kernel's KNOCK comment);
-    // 4 = the four-k / eight-row-part layout (gru_bwd_pair_k4_kernel), 36 + k its knock-outs
-    static const int mode = getenv("SIR_BPTT") ? atoi(getenv("SIR_BPTT")) : 0;
+    // SIR_BPTT (A/B and timing knock-outs, profiles/r04/ab_bptt.txt; default 4 = the product kernel: four-k / eight-row-part layout,
+    // gru_bwd_pair_k4_kernel; 36 + k its knock-outs): 0 = the two-k kernel with the padded dgh image, 1 = round 3's unpadded image,
+    // 2 = two-k + product loop on v_pk_fma_f32, 3 = 1 + 2; 16 + k = knock-out k of the two-k kernel (see the kernels' KNOCK comments)
+    static const int mode = getenv("SIR_BPTT") ? atoi(getenv("SIR_BPTT")) : 4;
     typedef void (*kern_t)(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, int, int, float*,
                            unsigned int*, unsigned);
-    kern_t kern = gru_bwd_pair_kernel<0, true, false>;
+    kern_t kern = gru_bwd_pair_k4_kernel<0>;
     switch (mode) {
+        case 0: kern = gru_bwd_pair_kernel<0, true, false>; break;
         case 1: kern = gru_bwd_pair_kernel<0, false, false>; break;
         case 2: kern = gru_bwd_pair_kernel<0, true, true>; break;
         case 3: kern = gru_bwd_pair_kernel<0, false, true>; break;

@@ -35,7 +35,7 @@ constexpr int GQ_NPL = 2;                 // h planes: hi, scaled residual
 constexpr int GQ_BUFB = GQ_NPL * GQ_PLANEB;    // one parity buffer: 16,896 B
 constexpr size_t GQ_LDS_BYTES = 2 * (size_t)GQ_BUFB;
 constexpr unsigned GQ_SPIN_LIMIT = 1u << 22;
-constexpr int GQ_POLL_DELAY = 16;          // default, x 64 cycles between the granule stores and the first poll round (see the poll loop); passed in dbg bits 8-12
+constexpr int GQ_POLL_DELAY = 8;           // default (16 before the f16x3 step got shorter: profiles/r04/ab_gq_delay.txt), x 64 cycles between the granule stores and the first poll round (see the poll loop); passed in dbg bits 8-12
 constexpr size_t GQ_XBUF_PER_CLUSTER = (size_t)2 * 4 * GQ_NU * GQ_UQ * 8;   // [parity][quarter][wave][store 0 | 1][lane][2] granules (producer-thread order)
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));

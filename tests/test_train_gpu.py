@@ -493,6 +493,39 @@ def test_training_step_at_bench_batch_256_vs_oracle(sd):
         assert torch.quantile(d[:: max(1, d.numel() // 100000)], 0.99).item() <= 2e-6 and d.max().item() <= 2.1 * cases.LR, name
 
 
+def test_bench_configuration_batch_256_with_dropout_vs_oracle(sd):
+    """The configuration bench.py times -- B = 256 AND dropout 0.5: layer 1's input gradient then runs as two K halves whose
+    ordered add applies the dropout mask (``dx_halves_add_kernel``), a branch the B = 8 / 64 dropout tests never reach
+    (ADVICE r3).  Host-rebuilt mask, oracle at the device's z / y, all 29 gradients at 2e-3 * rms."""
+    bsz, t, s, p = 256, 200, 25, 0.5
+    x = cases.varied_features(bsz, t, seed=258)
+    y = synth.synth_labels(bsz, 31, seed=259)
+    m = _model(sd, dropout=p)
+    logits = m(x.to(DEV))
+    loss = train_ops.fused_cross_entropy(logits, y.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    seed, p_used = m._sir_last_dropout
+    assert p_used == p
+    keep = torch.from_numpy(host_rng.dropout_keep(seed, bsz * s * 512, p)).view(bsz, s, 512)
+    mask = keep.float() / (1.0 - p)
+    v = _views(m, bsz, t)
+    dy0 = v["dy0"] / _loss_scale(bsz)                                     # gradient wrt the un-dropped layer-0 output
+    assert (dy0[~keep] == 0).all() and (dy0[keep] != 0).float().mean() > 0.99     # the mask reached the split-K add
+    zo, yo = _device_forward_values(m, sd, x, bsz, t, v)
+    del v
+    st = {}
+    ref_loss, ref_grads, _, ref_logits = model_ref.loss_and_grads(sd, x, y, dropout_mask=mask, z_override=zo, y_override=yo, stages=st)
+    del zo, yo
+    assert abs(loss.item() - ref_loss.item()) < 2e-5
+    assert (logits.detach().cpu() - ref_logits).abs().max() < 5e-5
+    assert _rel(dy0, st["d_gru_l0"])[0] < 2e-3
+    gerr = _grad_errors(m, ref_grads)
+    print("B=256 dropout-on grad errors:", {k: f"{e:.1e}" for k, e in gerr.items()})
+    for k, e in gerr.items():
+        assert e < 2e-3 or k == "attention.bias", (k, e)
+
+
 def _host_augmented(wave, lengths, shifts, sigmas, seed):
     out = []
     for b in range(wave.shape[0]):
