@@ -443,7 +443,8 @@ def dropin_epoch_leg(model, opt, fz, dev, step_rate, n_clips, batch=BATCH, worke
     a synthetic split of `n_clips` 3 s clips, per route, as utterances/s and as a fraction of the bare step rate (`train.value`):
       dataloader        train_epoch() (train.py:72-118) over FSCIntentDataset + DataLoader(batch 256, num_workers 8, pin_memory)
                         + collate_fn on a feature cache in the reference's file format (train.py:203-219, dataset.py:78-115)
-      dataloader_staged the same with pin_memory=False: the batches go through train_epoch's persistent pinned ring (HostStager)
+      dataloader_forkserver  the same dataset through the DataLoader as train() builds it with `hbm_feature_cache: false`: fork-server
+                        workers (persistent), pin_memory=False, batches through train_epoch's persistent pinned ring (HostStager)
       hbm_feature_store the same cache staged once in HBM (sir_amd/feature_store.py), train_epoch() over its batches: train()'s
                         default route
       waveform_store    train_epoch_waveforms() over WaveformStore on the same clips (`fused_features: true`)
@@ -530,20 +531,21 @@ def dropin_epoch_leg(model, opt, fz, dev, step_rate, n_clips, batch=BATCH, worke
                       f"batch; the loader alone, with an idle main thread, delivers {r['loader_only_steady_utts_per_s']:.0f} utt/s"
                       if r["waiting_for_batches_s"] > 0.5 * r["epoch_s"] else "the GPU step")
         r["limit"] = ("the loader's own pinning: " + r["limit"]) if r["limit"] != "the GPU step" else (
-            "host -> device hand-over, not batch assembly: the step loop waits for batches only "
-            f"{r['waiting_for_batches_s']:.2f} s of {r['epoch_s']:.2f} s; with pin_memory=True torch's pinning thread allocates a pinned "
-            "block per batch, which stalls while the GPU is busy (devtools/dataloader_probe.py: 3 k utt/s with any kernel in flight, "
-            "112 k with an idle GPU)")
+            "GPU submission from a process with FORKED children, not batch assembly: the step loop waits for batches only "
+            f"{r['waiting_for_batches_s']:.2f} s of {r['epoch_s']:.2f} s; while the DataLoader's forked workers live, every kernel launch "
+            "of the parent is ~50x slower (devtools/dataloader_probe.py, profiles/r04/dataloader_probe.txt: 3 k utt/s with fork, 34 k "
+            "with fork-server workers, any consumer that launches a kernel)")
         out["dataloader"] = r
-        # the same route as train() builds it when `hbm_feature_cache: false`: pin_memory=False, batches staged by train_epoch's own
-        # persistent pinned ring (scripts/train.py::HostStager)
-        def loader_np(_e):
-            return DataLoader(ds, batch_size=batch, shuffle=True, num_workers=workers, collate_fn=tr.collate_fn, pin_memory=False)
-        r = run(loader_np, lambda it: tr.train_epoch(model, it, opt, crit, dev))
-        r["limit"] = ("host batch assembly (worker __getitem__ + collate_fn + shared-memory hand-over + CPU copy into the pinned ring): "
+        # the same route as train() builds it when `hbm_feature_cache: false` (scripts/train.py::loader_kwargs): workers from a fork
+        # server (they do not inherit the HIP-initialised parent), kept alive across the epochs, pin_memory=False, batches staged by
+        # train_epoch's own persistent pinned ring (HostStager)
+        fs_loader = DataLoader(ds, batch_size=batch, shuffle=True, collate_fn=tr.collate_fn, **tr.loader_kwargs(workers))
+        r = run(lambda _e: fs_loader, lambda it: tr.train_epoch(model, it, opt, crit, dev))
+        del fs_loader
+        r["limit"] = ("host batch assembly (worker __getitem__ + collate_fn + shared-memory hand-over): "
                       f"{r['waiting_for_batches_s']:.2f} s of the {r['epoch_s']:.2f} s epoch are spent waiting for the DataLoader"
-                      if r["waiting_for_batches_s"] > 0.4 * r["epoch_s"] else "the step loop's own host work (13 MB CPU copy per batch into the pinned ring) + the GPU step")
-        out["dataloader_staged"] = r
+                      if r["waiting_for_batches_s"] > 0.4 * r["epoch_s"] else "the step loop's own host work + the GPU step")
+        out["dataloader_forkserver"] = r
         del ds
         # ---- route 2: the cache staged in HBM (train()'s default) ----
         t0 = time.perf_counter()

@@ -20,21 +20,21 @@ NAME_MAP = [
     # training-only instantiations first (substring match, first hit wins)
     # second-generation Winograd kernel <CIN, COUT, OUT_MODE, ...>: mode 2 = training forward, 3 = data gradient, 0 / 1 = inference
     ("conv3x3_wino2_bf16x6_kernel<32, 64, 2", "train_conv2_fwd"), ("conv3x3_wino2_bf16x6_kernel<64, 128, 2", "train_conv3_fwd"),
-    ("conv3x3_wino2_bf16x6_kernel<128, 64, 3", "bwd_conv3_dgrad"),
+    ("conv3x3_wino2_bf16x6_kernel<128, 64, 3", "bwd_conv3_dgrad"), ("conv3x3_wino2_bf16x6_kernel<64, 32, 3", "bwd_conv2_dgrad"),
     ("conv3x3_wino2_bf16x6_kernel<32, 64, 0", "conv2_mfma_bn_relu_pool"), ("conv3x3_wino2_bf16x6_kernel<64, 128, 1", "conv3_mfma_bn_relu_pool"),
     ("conv3x3_wino_bf16x6_kernel<128, 64", "bwd_conv3_dgrad"),
     ("conv3x3_wino_bf16x6_kernel<32, 64, 2", "train_conv2_fwd"), ("conv3x3_bf16x6_ns_kernel<64, 128, 2, 2, 2", "train_conv3_fwd"),
     ("conv3x3_bf16x6_ns_kernel<64, 32", "bwd_conv2_dgrad"), ("conv3x3_bf16x6_ns_kernel<128, 64", "bwd_conv3_dgrad"),
-    ("conv_wgrad_wino_bf16x6_kernel<32, 64>", "bwd_conv2_wgrad"), ("conv_wgrad_wino_bf16x6_kernel<64, 128>", "bwd_conv3_wgrad"),
+    ("conv_wgrad_wino_bf16x6_kernel<32, 64", "bwd_conv2_wgrad"), ("conv_wgrad_wino_bf16x6_kernel<64, 128", "bwd_conv3_wgrad"),
     ("conv_wgrad_bf16x6_kernel<32, 64>", "bwd_conv2_wgrad"), ("conv_wgrad_bf16x6_kernel<64, 128>", "bwd_conv3_wgrad"),
-    ("gru_quad_kernel<true>", "train_gru"), ("gru_bwd_pair_kernel", "bwd_gru"),
+    ("gru_quad_kernel<true>", "train_gru"), ("gru_bwd_pair_kernel", "bwd_gru"), ("gru_bwd_pair_k4_kernel", "bwd_gru"),
     ("gemm_tn2_bf16x6_kernel<true", "bwd_gru_dw"), ("gemm_tn2_bf16x6_kernel<false", "bwd_gru_dx"),
     ("gemm_tn_bf16x6_kernel<true", "bwd_gru_dw"), ("gemm_tn_bf16x6_kernel<false", "bwd_gru_dx"),
     ("bn_bwd_dz_kernel<false>", "bwd_bn2_dz"), ("bn_bwd_dz_kernel<true>", "bwd_bn3_dz"), ("conv1_bwd_kernel", "bwd_conv1"),
     ("feat_utt_kernel", "feat_frames"), ("feat_frames_kernel", "feat_frames"), ("feat_normalise_kernel", "feat_normalise"),
     ("conv1_mfma_bn_relu_pool_kernel", "conv1_bn_relu_pool"), ("conv1_bn_relu_pool_kernel", "conv1_bn_relu_pool"),
     ("conv3x3_wino_bf16x6_kernel<32, 64", "conv2_mfma_bn_relu_pool"), ("conv3x3_bf16x6_ns_kernel<32, 64", "conv2_mfma_bn_relu_pool"), ("conv3x3_bf16x6_ns_kernel<64, 128", "conv3_mfma_bn_relu_pool"),
-    ("gemm_nt_bf16x6_v3_kernel", "gemm_ih"),
+    ("gemm_nt_bf16x6_v3_kernel", "gemm_ih"), ("gemm_nt_f16x3_kernel", "gemm_ih"),
     ("conv3x3_bf16x6_kernel<32, 64", "conv2_mfma_bn_relu_pool"), ("conv3x3_bf16x6_kernel<64, 128", "conv3_mfma_bn_relu_pool"),
     ("conv3x3_mfma_kernel<32, 64", "conv2_mfma_bn_relu_pool"), ("conv3x3_mfma_kernel<64, 128", "conv3_mfma_bn_relu_pool"),
     ("gemm_nt_bf16x6_kernel", "gemm_ih"), ("gemm_nt_bias_kernel", "gemm_ih"), ("gru_recurrence_kernel", "gru_recurrence"), ("gru_pair_kernel", "gru_recurrence"), ("gru_quad_kernel", "gru_recurrence"),
@@ -53,6 +53,8 @@ def main(src, dst):
                     vals[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
                     break
     out = {}
+    if "gemm_ih" in vals:                             # (both layers' launches averaged)
+        vals["gemm_ih_l0"] = vals["gemm_ih_l1"] = vals["train_gemm_ih_l0"] = vals["train_gemm_ih_l1"] = vals["gemm_ih"]
     if "gru_recurrence" in vals:                      # one kernel, two launches per step: bench.py reports them per layer
         vals["gru_recurrence_l0"] = vals["gru_recurrence_l1"] = vals["gru_recurrence"]
     for both, names in (("train_gru", ("train_gru_l0", "train_gru_l1")), ("bwd_gru", ("bwd_gru_l0", "bwd_gru_l1"))):

@@ -49,8 +49,8 @@ ROWS = [
     ("conv3x3_wino_bf16x6_kernel<128, 64", "bwd conv3 dgrad (Winograd)", "train", "mfma6", F["bwd_conv3_dgrad"] * B, Z3 + A2),
     ("conv3x3_bf16x6_ns_kernel<64, 32", "bwd conv2 dgrad (direct)", "train", "mfma6", F["bwd_conv2_dgrad"] * B, Z2 + A1),
     ("conv3x3_bf16x6_ns_kernel<128, 64", "bwd conv3 dgrad (direct)", "train", "mfma6", F["bwd_conv3_dgrad"] * B, Z3 + A2),
-    ("conv_wgrad_wino_bf16x6_kernel<32, 64>", "bwd conv2 wgrad (Winograd)", "train", "mfma6", F["bwd_conv2_wgrad"] * B, A1 + Z2),
-    ("conv_wgrad_wino_bf16x6_kernel<64, 128>", "bwd conv3 wgrad (Winograd)", "train", "mfma6", F["bwd_conv3_wgrad"] * B, A2 + Z3),
+    ("conv_wgrad_wino_bf16x6_kernel<32, 64", "bwd conv2 wgrad (Winograd)", "train", "mfma6", F["bwd_conv2_wgrad"] * B, A1 + Z2),
+    ("conv_wgrad_wino_bf16x6_kernel<64, 128", "bwd conv3 wgrad (Winograd)", "train", "mfma6", F["bwd_conv3_wgrad"] * B, A2 + Z3),
     ("conv_wgrad_bf16x6_kernel<32, 64>", "bwd conv2 wgrad", "train", "mfma6", F["bwd_conv2_wgrad"] * B, A1 + Z2),
     ("conv_wgrad_bf16x6_kernel<64, 128>", "bwd conv3 wgrad", "train", "mfma6", F["bwd_conv3_wgrad"] * B, A2 + Z3),
     ("gru_quad_kernel<true>", "train GRU recurrence (l0, l1)", "train", "mfma6", F["train_gru_l0"] * B, GI + Y + B * S * 2048 * 4),

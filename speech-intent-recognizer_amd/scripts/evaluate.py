@@ -68,8 +68,9 @@ def evaluate(args, config):
     test_dataset = FSCIntentDataset(csv_path=args.test_csv, label_map_path=args.label_map, is_training=False,
                                     use_cache=config.get("use_feature_cache", True),
                                     cache_dir=config.get("cache_dir", "data/cached_features"))
-    test_loader = DataLoader(test_dataset, batch_size=config.get("batch_size", 32), shuffle=False,
-                             num_workers=config.get("num_workers", 4), collate_fn=collate_fn, pin_memory=False)
+    from sir_amd.scripts.train import loader_kwargs
+    test_loader = DataLoader(test_dataset, batch_size=config.get("batch_size", 32), shuffle=False, collate_fn=collate_fn,
+                             **loader_kwargs(config.get("num_workers", 4)))
     logger.info("Starting evaluation...")
     all_preds, all_labels = predict_loader(model, test_loader, device)
 

@@ -86,6 +86,20 @@ class HostStager:
         return out
 
 
+def loader_kwargs(num_workers):
+    """How this package builds its DataLoaders (the ``hbm_feature_cache: false`` route of ``train()``, ``evaluate()``):
+    * ``pin_memory=False`` -- host batches go through ``HostStager``'s persistent pinned ring instead of torch's per-batch pinning;
+    * worker processes from a FORK SERVER, kept alive across epochs.  The reference's ``DataLoader(num_workers=8)`` forks its
+      workers from the training process (train.py:203-219); on this stack, children forked from a process that has initialised
+      HIP slow that process's GPU submissions ~50x for as long as they live (a 2 ms training step takes 70-100 ms: 3 k
+      utterances/s; the same loader with fork-server workers: 34 k -- profiles/r04/dataloader_probe.txt).  Fork-server workers
+      start from a clean process; the dataset travels to them by pickle once (``persistent_workers``)."""
+    kw = dict(num_workers=num_workers, pin_memory=False)
+    if num_workers > 0:
+        kw.update(multiprocessing_context="forkserver", persistent_workers=True)
+    return kw
+
+
 def train_epoch(model, train_loader, optimizer, criterion, device, scaler=None):
     """One epoch (train.py:72-118); returns the mean of the per-step losses.  ``scaler`` is accepted
     for signature compatibility: the HIP path always computes in fp32 (the parity target is the fp32
@@ -279,11 +293,9 @@ def train(args, config):
     seed = int(config.get("seed", 0))
     train_sampler = train_ops.ShardSampler(len(train_dataset), rank, world, shuffle=True, seed=seed)
     val_sampler = train_ops.ShardSampler(len(val_dataset), rank, world, shuffle=False, pad=False)
-    # (pin_memory=False: train_epoch / validate stage host batches through their own persistent pinned ring, see HostStager)
-    train_loader = None if (fused or hbm_cache) else DataLoader(train_dataset, batch_size=bs, sampler=train_sampler, num_workers=nw,
-                                                                collate_fn=collate_fn, pin_memory=False)
-    val_loader = None if hbm_cache else DataLoader(val_dataset, batch_size=bs * 2, sampler=val_sampler, num_workers=nw,
-                                                   collate_fn=collate_fn, pin_memory=False)
+    lkw = loader_kwargs(nw)
+    train_loader = None if (fused or hbm_cache) else DataLoader(train_dataset, batch_size=bs, sampler=train_sampler, collate_fn=collate_fn, **lkw)
+    val_loader = None if hbm_cache else DataLoader(val_dataset, batch_size=bs * 2, sampler=val_sampler, collate_fn=collate_fn, **lkw)
 
     model = CNNAudioGRU(num_classes=config.get("num_labels", 31)).to(device)
     train_ops.broadcast_module_(model)             # identical initial weights / BN buffers on every rank

@@ -83,6 +83,9 @@ def test_precompute_dataset_train_evaluate(tmp_path):
     args = types.SimpleNamespace(train_csv=csvs["train"], val_csv=csvs["valid"], label_map=str(lm))
     best = tr.train(args, cfg)
     assert 0.0 <= best <= 1.0
+    # the DataLoader route (fork-server workers + the pinned staging ring) instead of the HBM feature store
+    best_dl = tr.train(args, dict(cfg, hbm_feature_cache=False, epochs=1, save_path=str(tmp_path / "ckpt_dl")))
+    assert 0.0 <= best_dl <= 1.0
     ckpt = os.path.join(cfg["save_path"], "best_model.pt")
     if best > 0:
         sd = torch.load(ckpt)
@@ -276,6 +279,9 @@ def test_train_from_waveforms_with_fused_augmentation(tmp_path):
     args = types.SimpleNamespace(train_csv=csvs["train"], val_csv=csvs["valid"], label_map=lm)
     best = tr.train(args, cfg)
     assert 0.0 <= best <= 1.0
+    # the DataLoader route (fork-server workers + the pinned staging ring) instead of the HBM feature store
+    best_dl = tr.train(args, dict(cfg, hbm_feature_cache=False, epochs=1, save_path=str(tmp_path / "ckpt_dl")))
+    assert 0.0 <= best_dl <= 1.0
     aug = tr.make_waveform_augment(cfg, seed=1, epoch=0)
     kw = aug(0, 4, [48000, 30000, 16000, 700])
     assert set(kw) == {"shift", "noise_sigma", "noise_seed", "time_mask", "freq_mask"} and kw["shift"].shape == (4,)
