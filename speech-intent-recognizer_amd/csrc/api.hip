@@ -79,7 +79,7 @@ extern "C" int sir_create(const sir_feature_config* cfg, sir_handle** out) {
     h->cluster_seen = false; h->cluster_multi = false; h->cluster_run = 0;
     h->cluster_always = getenv("SIR_CLUSTER_EVENTS") && atoi(getenv("SIR_CLUSTER_EVENTS")) == 1;   // A/B switch: chained mode throughout
     if (h->cluster_always) h->cluster_multi = true;
-    h->attr_gemm_v3 = h->attr_gru_quad = h->attr_gru_bwd = h->attr_tn = h->attr_wgrad = false;
+    h->attr_gemm_v3 = h->attr_gru_quad = h->attr_gru_bwd = h->attr_gru_bwd_quad = h->attr_tn = h->attr_wgrad = false;
     for (auto& a : h->attr_wino2) a = false;
     h->zero_page = nullptr; h->num_cus = 256;
     for (auto& x : h->xbufs) { x.st = nullptr; x.p = nullptr; x.kind = 0; x.cap = 0; x.bytes = 0; x.epoch = 0; x.used = 0; }

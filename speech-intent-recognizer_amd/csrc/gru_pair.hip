@@ -1,15 +1,20 @@
-// Launcher of the paired-workgroup GRU backward recurrence (gru_bwd_pair_kernel.h).  Own translation unit because it is
+// Launcher of the GRU backward recurrence: the matrix-core cluster kernel (gru_quad.hip) by default, else the paired-workgroup
+// fp32-FMA kernels (gru_bwd_pair_kernel.h).  Own translation unit because it is
 // compiled with -fno-slp-vectorize: hipcc's SLP pass packs the scalar fmaf chains into v_pk_fma_f32, whose register-pair
 // constraints cost ~180 spilled VGPRs in this register-resident kernel.
 #include <cstdlib>
 #include "gru_bwd_pair_kernel.h"
 
 int sir_launch_gru_bwd_pair(sir_handle* h, hipStream_t st, const float* dy, const float* gates, const float* y, const float* whh0,
-                            const float* whh1, float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S) {
-    // SIR_BPTT (A/B and timing knock-outs, profiles/r04/ab_bptt.txt; default 4 = the product kernel: four-k / eight-row-part layout,
-    // gru_bwd_pair_k4_kernel; 36 + k its knock-outs): 0 = the two-k kernel with the padded dgh image, 1 = round 3's unpadded image,
-    // 2 = two-k + product loop on v_pk_fma_f32, 3 = 1 + 2; 16 + k = knock-out k of the two-k kernel (see the kernels' KNOCK comments)
-    static const int mode = getenv("SIR_BPTT") ? atoi(getenv("SIR_BPTT")) : 4;
+                            const float* whh1, float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S, const void* wfrag0,
+                            const void* wfrag1) {
+    // wfrag0 / 1: the matrix-core kernel's resident fragments (gru_frag_prep.h; optional, used by mode 5 only)
+    // SIR_BPTT (A/B and timing knock-outs, profiles/r04/ab_bptt.txt; default 5 = the matrix-core kernel, clusters of four workgroups x
+    // 16 utterances, gru_bwd_quad_kernel.h): 4 = the fp32-FMA kernel in its four-k / eight-row-part layout (gru_bwd_pair_k4_kernel; 36 + k
+    // its knock-outs), 0 = the two-k kernel with the padded dgh image, 1 = round 3's unpadded image, 2 = two-k + product loop on
+    // v_pk_fma_f32, 3 = 1 + 2; 16 + k = knock-out k of the two-k kernel (see the kernels' KNOCK comments)
+    static const int mode = getenv("SIR_BPTT") ? atoi(getenv("SIR_BPTT")) : 5;
+    if (mode == 5) return sir_launch_gru_bwd_quad(h, st, dy, gates, y, whh0, whh1, dgi, dgh, bsum_i, bsum_h, B, S, wfrag0, wfrag1);
     typedef void (*kern_t)(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, int, int, float*,
                            unsigned int*, unsigned);
     kern_t kern = gru_bwd_pair_k4_kernel<0>;

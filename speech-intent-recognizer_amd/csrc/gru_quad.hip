@@ -1,6 +1,7 @@
 // Launcher of the quad-workgroup MFMA GRU recurrence (gru_quad_kernel.h).
 #include <stdlib.h>
 #include "gru_quad_kernel.h"
+#include "gru_bwd_quad_kernel.h"
 
 int sir_launch_gru_quad(sir_handle* h, hipStream_t st, bool save, const float* gi, const float* whh0, const float* whh1, const float* bhh0,
                         const float* bhh1, float* y, int B, int S, float* gates, unsigned short* yplanes, const void* wfrag0,
@@ -32,7 +33,30 @@ int sir_launch_gru_quad(sir_handle* h, hipStream_t st, bool save, const float* g
     return SIR_OK;
 }
 
-// inference-side preparation of one direction's resident fragments (768 x 256 x 6 bytes)
+// inference-side preparation of one direction's resident fragments (GRU_FRAG_BYTES)
 void sir_prep_whh_quad(hipStream_t st, const float* whh, void* frag) {
-    hipLaunchKernelGGL(prep_whh_quad_kernel, dim3(4 * 4 * 3 * 8 * 64 / 256), dim3(256), 0, st, whh, (uint4*)frag);
+    hipLaunchKernelGGL(prep_whh_quad_kernel, dim3(GQ_FRAG_THREADS / 256), dim3(256), 0, st, whh, (uint4*)frag);
+}
+
+// BPTT on the matrix cores, clusters of four workgroups x 16 utterances (gru_bwd_quad_kernel.h); same contract as sir_launch_gru_bwd_pair
+int sir_launch_gru_bwd_quad(sir_handle* h, hipStream_t st, const float* dy, const float* gates, const float* y, const float* whh0,
+                            const float* whh1, float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S, const void* wfrag0,
+                            const void* wfrag1) {
+    if (!h->attr_gru_bwd_quad) {
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_bwd_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BQ_LDS_BYTES));
+        h->attr_gru_bwd_quad = true;
+    }
+    if (S >= 65535) { sir_set_error("gru_bwd_quad: %d steps exceed the 16-bit step field of the granule tag", S); return SIR_EUNSUPPORTED; }
+    const int clusters = ((B + GQ_NU - 1) / GQ_NU) * 2;
+    unsigned epoch = 0;
+    void* xbuf = nullptr;
+    if (sir_xbuf_acquire(h, st, 3, (size_t)clusters * BQ_XBUF_PER_CLUSTER, 0xFFFFu, &xbuf, &epoch) != SIR_OK) return SIR_EHIP;
+    // SIR_BQ_DBG: timing knock-outs of gru_bwd_quad_kernel (see its `dbg` comment), 0 in production; SIR_BQ_DELAY: first poll's delay
+    static const int dbg0 = getenv("SIR_BQ_DBG") ? atoi(getenv("SIR_BQ_DBG")) : 0;
+    static const int delay = getenv("SIR_BQ_DELAY") ? atoi(getenv("SIR_BQ_DELAY")) & 31 : GQ_POLL_DELAY;
+    const int dbg = (dbg0 & 255) | (delay << 8);
+    hipLaunchKernelGGL(gru_bwd_quad_kernel, dim3(4 * (unsigned)clusters), dim3(GQ_THREADS), BQ_LDS_BYTES, st, dy, gates, y, whh0, whh1, dgi, dgh,
+                       bsum_i, bsum_h, B, S, (unsigned long long*)xbuf, h->status, epoch, dbg, (const uint4*)wfrag0, (const uint4*)wfrag1);
+    SIR_HIP_TRY(hipGetLastError());
+    return SIR_OK;
 }

@@ -24,15 +24,18 @@
 // Results differ from the fp32-FMA kernel only by the bf16x6 product rounding (~2^-24 relative per product).
 #pragma once
 #include "bf16x6_kernels.h"
+#include "gru_frag_prep.h"
 
 typedef unsigned int gq_u32x4 __attribute__((ext_vector_type(4)));   // native vector: usable as an inline-asm operand
 constexpr int GQ_NU = 16;                 // utterances per cluster (the MFMA N dimension)
 constexpr int GQ_UQ = 64;                 // hidden units per workgroup
 constexpr int GQ_THREADS = 256;
-constexpr int GQ_ROWB = 256 * 2 + 16;     // bytes per utterance row of one h plane (pad: conflict-free b128 reads)
+constexpr int GQ_ROWB = 256 * 2 + 32;     // bytes per utterance row of one h plane: 34 sixteen-byte slots = 2 mod 16 puts the 16 lanes of every
+                                          // ds_read_b128 group ({0-3, 12-15, 20-27}, ...) on 16 different slots; with + 16 (rounds 2-3) lanes
+                                          // (n, kg) = (12, 0) and (11, 1) of one group shared a slot (PMC r04: conflict ratio 0.49)
 constexpr int GQ_PLANEB = GQ_NU * GQ_ROWB;
 constexpr int GQ_NPL = 2;                 // h planes: hi, scaled residual
-constexpr int GQ_BUFB = GQ_NPL * GQ_PLANEB;    // one parity buffer: 16,896 B
+constexpr int GQ_BUFB = GQ_NPL * GQ_PLANEB;    // one parity buffer: 17,408 B
 constexpr size_t GQ_LDS_BYTES = 2 * (size_t)GQ_BUFB;
 constexpr unsigned GQ_SPIN_LIMIT = 1u << 22;
 constexpr int GQ_POLL_DELAY = 8;           // default (16 before the f16x3 step got shorter: profiles/r04/ab_gq_delay.txt), x 64 cycles between the granule stores and the first poll round (see the poll loop); passed in dbg bits 8-12
@@ -51,20 +54,11 @@ __device__ __forceinline__ float gq_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x));
 }
 
-// W_hh of one direction as the kernel's resident MFMA fragments: [quarter][wave][gate][k-step][plane (hi, lo')][lane] uint4
-// (inference prepares this once per weights version; the kernel prologue is then 72 coalesced 16-byte loads per lane
-// instead of 48 row-strided fp32 loads and the split)
+// W_hh of one direction as the kernel's resident MFMA fragments (gru_frag_prep.h: [quarter][wave][gate][k-step][plane][lane] uint4);
+// inference prepares this once per weights version, training once per step inside train_prep_kernel: the kernel prologue is then
+// 48 coalesced 16-byte loads per lane instead of 48 row-strided fp32 loads and the split
 static __global__ __launch_bounds__(256) void prep_whh_quad_kernel(const float* __restrict__ whh, uint4* __restrict__ frag) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;              // ((((q*4 + wv)*3 + g)*8 + s)*64 + lane)
-    if (idx >= 4 * 4 * 3 * 8 * 64) return;
-    const int lane = idx & 63, s = (idx >> 6) & 7, g = (idx >> 9) % 3, qw = idx / (64 * 8 * 3), wv = qw & 3, q = qw >> 2;
-    const float* wrow = whh + (size_t)(g * 256 + q * 64 + wv * 16 + (lane & 15)) * 256 + s * 32 + (lane >> 4) * 8;
-    uint2 h0, l0, h1, l1;
-    split2h_quad(*reinterpret_cast<const float4*>(wrow), h0, l0);
-    split2h_quad(*reinterpret_cast<const float4*>(wrow + 4), h1, l1);
-    uint4* o = frag + ((size_t)(((qw * 3 + g) * 8 + s) * GQ_NPL) * 64 + lane);
-    o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-    o[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    prep_whh_quad_elem(whh, frag, blockIdx.x * 256 + threadIdx.x);
 }
 
 // xbuf   [clusters][2 parity][4 quarters][16 utterances][64 units] 8-byte granules; the 16-bit tag is {7-bit launch epoch of

@@ -4,6 +4,7 @@
 #include "f16x3_kernels.h"
 #include "conv_wino_bf16x6_kernel.h"
 #include "conv_wino2_bf16x6_kernel.h"
+#include "gru_frag_prep.h"
 
 namespace {
 
@@ -18,7 +19,7 @@ enum WsBuf {
     WS_WP2,      // (unused, kept so that the buffer indices of sir_model_workspace_offsets stay put)
     WS_WP3,      // (unused)
     WS_BN,       // folded BN: scale[224] then shift[224] (channels of bn1|bn2|bn3)
-    WS_WHT,      // W_hh fragments of the recurrence kernel, [4 (layer, direction)][768 * 256 * 6 bytes]
+    WS_WHT,      // W_hh fragments of the recurrence kernel, [4 (layer, direction)][GRU_FRAG_BYTES]
     WS_XS,       // f16x2 planes (f16_split.h) of the current GEMM A operand, [2][B*S][1024] fp16
     WS_WS,       // f16x2 planes of W_ih: l0 [2 directions][2][768][1024], l1 [2][2][768][512]
     WS_WCB,      // bf16x3 planes of the conv2 / conv3 weights
@@ -49,7 +50,7 @@ void ws_sizes(const Dims& d, size_t* bytes) {
     bytes[WS_WP2] = 0;
     bytes[WS_WP3] = 0;
     bytes[WS_BN] = (size_t)2 * 224 * 4;
-    bytes[WS_WHT] = (size_t)4 * 768 * 256 * 6;                  // W_hh as the resident bf16x3 MFMA fragments of the recurrence kernel
+    bytes[WS_WHT] = 4 * GRU_FRAG_BYTES;                         // W_hh as the resident f16x2 MFMA fragments of the recurrence kernel
     bytes[WS_XS] = B * d.S * 1024 * 2 * 2;
     bytes[WS_WS] = ((size_t)2 * 2 * 768 * 1024 + (size_t)2 * 2 * 768 * 512) * 2;
     bytes[WS_WCB] = ((size_t)3 * 32 * 16 * 64 + (size_t)3 * 64 * 16 * 128 + (size_t)3 * 64 * 9 * 128) * 2;   // conv2, conv3: 16 Winograd frequencies per (cout, cin); conv3 again with 9 taps for the direct kernel (shapes the Winograd kernel does not cover)
@@ -146,7 +147,7 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
         for (int i = 0; i < 3; ++i)
             hipLaunchKernelGGL(prep_bn_kernel, dim3(1), dim3(128), 0, st, w->bn_w[i], w->bn_b[i], w->bn_mean[i], w->bn_var[i],
                                bns + bn_o[i], bnt + bn_o[i], bn_c[i]);
-        for (int i = 0; i < 4; ++i) sir_prep_whh_quad(st, w->gru_w_hh[i], (unsigned char*)wht + (size_t)i * 768 * 256 * 6);
+        for (int i = 0; i < 4; ++i) sir_prep_whh_quad(st, w->gru_w_hh[i], (unsigned char*)wht + (size_t)i * GRU_FRAG_BYTES);
         // (the weight planes are prepared in the arithmetic of the kernel that will read them: f16x3 for the second-generation
         // Winograd kernel's forward stages, bf16x3 for the first-generation / direct fallbacks)
         if (f16c2) hipLaunchKernelGGL(prep_conv_w_wino_f16x3_kernel, dim3((32 * 16 * 64 + 255) / 256), dim3(256), 0, st, w->conv_w[1], wcb2, 32, 64, h->status);
@@ -209,7 +210,7 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
         if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
         // layer 0 also writes the f16x2 planes of ITS output: the A operand of the layer-1 projection
         const int rc = sir_launch_gru_quad(h, st, false, gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], y0, B, S, nullptr,
-                                           xs, wht, (unsigned char*)wht + (size_t)768 * 256 * 6);
+                                           xs, wht, (unsigned char*)wht + GRU_FRAG_BYTES);
         if (rc != SIR_OK) return rc;
         if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP;
     }
@@ -222,7 +223,7 @@ extern "C" int sir_model_infer(sir_handle* h, const sir_model_weights* w, const 
         SirProfScope prof(h, SIR_K_GRU1, st);
         if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
         const int rc = sir_launch_gru_quad(h, st, false, gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], y1, B, S, nullptr,
-                                           nullptr, (unsigned char*)wht + (size_t)2 * 768 * 256 * 6, (unsigned char*)wht + (size_t)3 * 768 * 256 * 6);
+                                           nullptr, (unsigned char*)wht + 2 * GRU_FRAG_BYTES, (unsigned char*)wht + 3 * GRU_FRAG_BYTES);
         if (rc != SIR_OK) return rc;
         if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP;
     }

@@ -105,7 +105,8 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     const size_t bw = (size_t)(B * 16 * d.wp1 / 64 + 64) * 128;          // bn backward partials, generous
     if (bw > st) st = bw;
     n[TB_STATS] = 2 * st;
-    n[TB_WP2] = n[TB_WP3] = n[TB_WHT] = n[TB_WR4] = n[TB_WP2T] = n[TB_WP3T] = 64;   // (slots of removed kernel generations; indices kept)
+    n[TB_WP2] = n[TB_WP3] = n[TB_WP2T] = n[TB_WP3T] = 64;   // (slots of removed kernel generations; indices kept)
+    n[TB_WHT] = n[TB_WR4] = 4 * GRU_FRAG_BYTES / sizeof(float);      // W_hh of 2 layers x 2 directions as resident fragments: forward (WHT), backward (WR4)
     n[TB_DY1] = B * S * 512;
     n[TB_DY0] = B * S * 512;
     n[TB_DGI] = B * S * 1536;
@@ -285,9 +286,13 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
             add(0, w->gru_w_ih[dir], p.wsl0 + (size_t)dir * 2 * 768 * 1024, 1024, 768, 384);
             add(0, w->gru_w_ih[2 + dir], p.wsl1 + (size_t)dir * 2 * 768 * 512, 512, 768, 192);
         }
+        for (int i = 0; i < 4; ++i) {                        // W_hh (layer i / 2, direction i % 2) as the recurrences' resident fragments
+            add(8, w->gru_w_hh[i], (char*)p.wht + (size_t)i * GRU_FRAG_BYTES, 0, 0, GQ_FRAG_THREADS / 256);
+            add(9, w->gru_w_hh[i], (char*)p.wr4 + (size_t)i * GRU_FRAG_BYTES, 0, 0, BQ_FRAG_THREADS / 256);
+        }
         pj.block0[nj] = blocks;
         pj.njobs = nj;
-        static_assert(PREP_MAX_JOBS >= 12, "job table");
+        static_assert(PREP_MAX_JOBS >= 18, "job table");
         hipLaunchKernelGGL(train_prep_kernel, dim3(blocks), dim3(256), 0, st, pj);
     }
     KCHECK();
@@ -356,7 +361,8 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
                        (const unsigned short*)(p.wsl0 + (size_t)2 * 768 * 1024), w->gru_b_ih[0], w->gru_b_ih[1], p.gi, 1536, M, 768, 1024)); }
     { SirProfScope prof(h, SIR_K_T_GRU0, st);
     if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
-    rc = sir_launch_gru_quad(h, st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0);
+    rc = sir_launch_gru_quad(h, st, true, p.gi, w->gru_w_hh[0], w->gru_w_hh[1], w->gru_b_hh[0], w->gru_b_hh[1], p.y0, B, S, p.g0, nullptr,
+                             (const char*)p.wht, (const char*)p.wht + GRU_FRAG_BYTES);
     if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP; }
     if (rc != SIR_OK) return rc;
     const float* y0in = p.y0;
@@ -372,7 +378,8 @@ extern "C" int sir_model_train_fwd(sir_handle* h, const sir_model_weights* w, fl
                        (const unsigned short*)(p.wsl1 + (size_t)2 * 768 * 512), w->gru_b_ih[2], w->gru_b_ih[3], p.gi, 1536, M, 768, 512)); }
     { SirProfScope prof(h, SIR_K_T_GRU1, st);
     if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
-    rc = sir_launch_gru_quad(h, st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1);
+    rc = sir_launch_gru_quad(h, st, true, p.gi, w->gru_w_hh[2], w->gru_w_hh[3], w->gru_b_hh[2], w->gru_b_hh[3], p.y1, B, S, p.g1, nullptr,
+                             (const char*)p.wht + 2 * GRU_FRAG_BYTES, (const char*)p.wht + 3 * GRU_FRAG_BYTES);
     if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP; }
     if (rc != SIR_OK) return rc;
     SirProfScope prof_head(h, SIR_K_T_HEAD, st);
@@ -527,7 +534,8 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         { SirProfScope prof(h, layer ? SIR_K_B_GRU1 : SIR_K_B_GRU0, st);
         if (sir_cluster_enter(h, st) != SIR_OK) return SIR_EHIP;
         rc = sir_launch_gru_bwd_pair(h, st, dy, gates, yout, w->gru_w_hh[2 * layer], w->gru_w_hh[2 * layer + 1], dgi_l, dgh_l, bsum_i, bsum_h,
-                                     B, S);
+                                     B, S, (const char*)p.wr4 + (size_t)(2 * layer) * GRU_FRAG_BYTES,
+                                     (const char*)p.wr4 + (size_t)(2 * layer + 1) * GRU_FRAG_BYTES);
         if (rc != SIR_OK) return rc;
         if (sir_cluster_leave(h, st) != SIR_OK) return SIR_EHIP;
         // bias gradients first: bsum_* alias the slab area used below

@@ -74,7 +74,7 @@ struct sir_handle {
     int cluster_run;                   // chained mode: launches in a row that came from cluster_stream
     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) latches, per handle = per device (a process-wide static would skip
     // the second device of a process that drives several)
-    bool attr_gemm_v3, attr_gru_quad, attr_gru_bwd, attr_tn, attr_wgrad;
+    bool attr_gemm_v3, attr_gru_quad, attr_gru_bwd, attr_gru_bwd_quad, attr_tn, attr_wgrad;
     bool attr_wino2[16];               // conv3x3_wino2_bf16x6_kernel instantiations (model_infer.hip / model_train.hip index them)
     float* zero_page;                  // 4 KB of zeros: DMA source of the second-generation Winograd kernel's out-of-image pixels
     int num_cus;                       // persistent kernels launch one workgroup per CU
@@ -218,6 +218,10 @@ int sir_features_launch(sir_handle* h, const void* wave, int wave_dtype, int64_t
 int sir_launch_gru_quad(sir_handle* h, hipStream_t st, bool save, const float* gi, const float* whh0, const float* whh1, const float* bhh0,
                         const float* bhh1, float* y, int B, int S, float* gates,
                         unsigned short* yplanes = nullptr, const void* wfrag0 = nullptr, const void* wfrag1 = nullptr);
-void sir_prep_whh_quad(hipStream_t st, const float* whh, void* frag);     // -> 768 * 256 * 6 bytes
+void sir_prep_whh_quad(hipStream_t st, const float* whh, void* frag);     // -> GRU_FRAG_BYTES (gru_frag_prep.h)
 int sir_launch_gru_bwd_pair(sir_handle* h, hipStream_t st, const float* dy, const float* gates, const float* y, const float* whh0,
-                            const float* whh1, float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S);
+                            const float* whh1, float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S,
+                            const void* wfrag0 = nullptr, const void* wfrag1 = nullptr);
+int sir_launch_gru_bwd_quad(sir_handle* h, hipStream_t st, const float* dy, const float* gates, const float* y, const float* whh0,
+                            const float* whh1, float* dgi, float* dgh, float* bsum_i, float* bsum_h, int B, int S,
+                            const void* wfrag0 = nullptr, const void* wfrag1 = nullptr);

@@ -4,6 +4,7 @@
 #include "model_kernels.h"
 #include "bf16x6_kernels.h"
 #include "conv_wino_bf16x6_kernel.h"
+#include "gru_frag_prep.h"
 
 // ------------------------------------------------------------------------------------------
 // BatchNorm with batch statistics
@@ -526,9 +527,9 @@ __device__ __forceinline__ void prep_whh_bwd_elem(const float* __restrict__ w, f
 // Every per-step re-layout of the weights (they change with each optimizer step) in ONE launch: a dozen ~5 us launches
 // otherwise.  kind 0: split2h_rows (a = ld_in = K, b = rows), 1: prep_conv_w_bf16x3 (a = cin, b = cout),
 // 2: prep_conv_wT_bf16x3 (a = cin_f, b = cout_f), 3: prep_whh_bwd, 4: prep_conv_w_wino_bf16x3 (a = cin, b = cout),
-// 5: prep_conv_wT_wino_bf16x3 (a = cin_f, b = cout_f), 6 / 7: the f16x3 forms of 4 / 5 (conv_wino_bf16x6_kernel.h).  Job j owns
-// blocks [block0[j], block0[j+1]).
-constexpr int PREP_MAX_JOBS = 12;
+// 5: prep_conv_wT_wino_bf16x3 (a = cin_f, b = cout_f), 6 / 7: the f16x3 forms of 4 / 5 (conv_wino_bf16x6_kernel.h), 8 / 9: W_hh as
+// the resident fragments of the forward / backward cluster recurrence (gru_frag_prep.h).  Job j owns blocks [block0[j], block0[j+1]).
+constexpr int PREP_MAX_JOBS = 20;
 struct PrepJobs {
     const float* src[PREP_MAX_JOBS];
     void* dst[PREP_MAX_JOBS];
@@ -551,6 +552,8 @@ static __global__ __launch_bounds__(256) void train_prep_kernel(PrepJobs jobs) {
         case 5: prep_conv_wT_wino_bf16x3_elem(src, (unsigned short*)jobs.dst[j], jobs.a[j], jobs.b[j], idx); break;
         case 6: prep_conv_w_wino_f16x3_elem(src, (unsigned short*)jobs.dst[j], jobs.a[j], jobs.b[j], idx, jobs.status); break;
         case 7: prep_conv_wT_wino_f16x3_elem(src, (unsigned short*)jobs.dst[j], jobs.a[j], jobs.b[j], idx, jobs.status); break;
+        case 8: prep_whh_quad_elem(src, (uint4*)jobs.dst[j], idx); break;
+        case 9: prep_whh_bwd_quad_elem(src, (uint4*)jobs.dst[j], idx); break;
         default: prep_whh_bwd_elem(src, (float*)jobs.dst[j], idx); break;
     }
 }
