@@ -55,7 +55,9 @@ int sir_f16_mask() {
 }
 
 int sir_bwd_streams() {
-    static const int m = getenv("SIR_BWD_STREAMS") ? atoi(getenv("SIR_BWD_STREAMS")) : 0;
+    // default 3: the weight-gradient launches of the backward run on a second stream owned by the handle (model_train.hip);
+    // 0 = everything on the caller's stream (profiles/r04/ab_bwd_streams.txt)
+    static const int m = getenv("SIR_BWD_STREAMS") ? atoi(getenv("SIR_BWD_STREAMS")) : 3;
     return m;
 }
 

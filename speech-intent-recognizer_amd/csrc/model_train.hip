@@ -29,6 +29,7 @@ enum TrainBuf {
     TB_GFL,       // paired GRU status word
     TB_C1M,       // conv1 input moments: 54 doubles (conv1_moments_kernel), forward -> backward
     TB_DGI1, TB_DGH1,   // gate gradients of GRU layer 1 (TB_DGI / TB_DGH hold layer 0's): layer 1's weight-gradient GEMM may run after layer 0's BPTT
+    TB_SLAB2,           // split-K slabs of the GRU weight-gradient GEMMs when they run on the side stream beside the BPTT of the layer below (SIR_BWD_STREAMS=2)
     TB_COUNT
 };
 
@@ -139,6 +140,13 @@ void tws_sizes(const TDims& d, size_t* n) {           // element counts (floats)
     n[TB_C1M] = 2 * C1_NMOM;
     n[TB_DGI1] = B * S * 1536;
     n[TB_DGH1] = B * S * 1536;
+    n[TB_SLAB2] = 64;
+    for (int in_sz : {1024, 512}) {
+        int t_, kc_, ns_;
+        size_t need;
+        tn_x6_plan(d.B * d.S, in_sz, &t_, &kc_, &ns_, &need);
+        if (need > n[TB_SLAB2]) n[TB_SLAB2] = need;
+    }
 }
 
 size_t tws_layout(const TDims& d, size_t* off) {
@@ -156,7 +164,7 @@ size_t tws_layout(const TDims& d, size_t* off) {
 
 struct TPtrs {
     float *a1, *z2, *a2, *z3, *x0, *gi, *g0, *g1, *y0, *y0d, *y1, *ctx, *bn, *bnb, *wp2, *wp3, *wht, *wr4, *wp2t, *wp3t;
-    float *dgi1, *dgh1;
+    float *dgi1, *dgh1, *slab2;
     float *dy1, *dy0, *dgi, *dgh, *dx0, *dz3, *da2, *dz2, *da1, *small, *slab;
     float2* stats;
     unsigned short *xs, *wsl0, *wsl1, *wcb2, *wcb3, *wcb2t, *wcb3t, *wcb3d;
@@ -186,6 +194,7 @@ TPtrs carve(void* ws, const size_t* off) {
     p.gfl = (unsigned int*)(b + off[TB_GFL]);
     p.c1m = (double*)(b + off[TB_C1M]);
     p.dgi1 = (float*)(b + off[TB_DGI1]); p.dgh1 = (float*)(b + off[TB_DGH1]);
+    p.slab2 = (float*)(b + off[TB_SLAB2]);
     return p;
 }
 
@@ -437,13 +446,14 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
     const float* y0in = dropout_p > 0.0f ? p.y0d : p.y0;
     const float gscale = sir_bwd_loss_scale(B), unscale = 1.0f / gscale;
 
-    // ---- two-stream form (SIR_BWD_STREAMS=1; A/B in profiles/r04/ab_bwd_streams.txt) ----------------------------------------
-    // The four big launches that nothing downstream waits for -- the GRU weight gradients of both layers and the two convolution
-    // weight gradients, with their slab reduces -- go to a stream owned by the handle: forked once behind the last dX (`ev_gru`),
-    // each convolution weight gradient behind the BatchNorm backward that produces its dz (`ev_dz3`, `ev_dz2`), joined once before
-    // the call returns (`ev_join`).  The chain BN3 -> dgrad3 -> BN2 -> dgrad2 -> conv1 stays on the caller's stream.  In the split
-    // form (SIR_BWD_HEAD_GRU / SIR_BWD_CNN, data parallel) the first half stays on one stream -- its gradients must be final when
-    // it returns -- and the second forks the convolution weight gradients only.
+    // ---- two-stream form (SIR_BWD_STREAMS, default 3; A/B in profiles/r04/ab_bwd_streams.txt) -------------------------------
+    // The launches that nothing downstream waits for -- the GRU weight gradients of both layers and the two convolution weight
+    // gradients, with their slab reduces -- go to a stream owned by the handle.  Each GRU weight-gradient GEMM forks right behind
+    // ITS layer's BPTT (bit 1 of the mode): layer 1's then runs beside layer 0's BPTT, which occupies half of the CUs and leaves the
+    // rest idle.  Each convolution weight gradient forks behind the BatchNorm backward that produces its dz (bit 0).  One join
+    // before the call returns.  The chain dX -> BN3 -> dgrad3 -> BN2 -> dgrad2 -> conv1 stays on the caller's stream.  In the split
+    // form (SIR_BWD_HEAD_GRU / SIR_BWD_CNN, data parallel) the first half joins before it returns -- its gradients are reduced
+    // next.  Mode 1 (round 4's first experiment): the GRU GEMMs fork once, behind the last dX.
     if (sir_bwd_streams() && !h->bwd_side) {                 // (first use: the only allocating step, as for the exchange buffers)
         SIR_HIP_TRY(hipStreamCreateWithFlags(&h->bwd_side, hipStreamNonBlocking));
         for (auto& e : h->bwd_ev) SIR_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -460,9 +470,17 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn2_bf16x6_kernel<false, 0, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn2_lds_bytes(false, 64)));
         h->attr_tn = true;
     }
-    const bool two = sir_bwd_streams() && h->bwd_side != nullptr;
+    // (while every kernel is being timed -- sir_profile_enable mode 1 -- the backward stays on one stream: per-kernel times of overlapped
+    // launches would say nothing about the kernels)
+    const bool two = sir_bwd_streams() && h->bwd_side != nullptr && h->prof_mode != 1;
     hipStream_t side = two ? h->bwd_side : st;
-    const bool defer_dw = two && part == SIR_BWD_ALL;
+    // SIR_BWD_STREAMS bits: 1 = the convolution weight gradients fork to the side stream (behind the BatchNorm backward that produces
+    // their dz), and in mode 1 the GRU weight-gradient GEMMs follow behind the last dX; 2 = the GRU weight-gradient GEMMs leave the
+    // caller's stream right behind THEIR layer's BPTT -- layer 1's then runs beside layer 0's BPTT, which keeps one workgroup on
+    // half of the CUs (gru_bwd_quad_kernel.h) and leaves the rest idle; 3 = both
+    const bool dw_beside = two && (sir_bwd_streams() & 2);
+    const bool fork_conv = two && (sir_bwd_streams() & 1);
+    const bool defer_dw = two && !dw_beside && part == SIR_BWD_ALL;
 
     // all four weight-gradient GEMMs of a GRU layer (2 directions x {W_ih, W_hh}) in one bf16x6 launch + the slab reduce
     auto launch_dw = [&](int layer, hipStream_t s_) -> int {
@@ -499,7 +517,7 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         tn_x6_plan(M, in_sz, &tiles_chk, &kchunk, &nsplit, &need);
         size_t pos = 0;
         for (int j = 0; j < 4; ++j) {
-            jb.slab[j] = p.slab + pos;
+            jb.slab[j] = (dw_beside ? p.slab2 : p.slab) + pos;
             jb.slab_stride[j] = sizes[j];
             pos += sizes[j] * nsplit;
         }
@@ -541,7 +559,12 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         // bias gradients first: bsum_* alias the slab area used below
         hipLaunchKernelGGL(gru_bias_colsum_kernel, dim3(24, 2), dim3(256), 0, st, (const float*)bsum_i, (const float*)bsum_h, B,
                            g->gru_b_ih[2 * layer], g->gru_b_ih[2 * layer + 1], g->gru_b_hh[2 * layer], g->gru_b_hh[2 * layer + 1], unscale); }
-        if (!defer_dw) { rc = launch_dw(layer, st); if (rc != SIR_OK) return rc; }
+        if (dw_beside) {                                     // (layer 0's GEMM queues behind layer 1's on the side stream: they share the slabs)
+            SIR_HIP_TRY(hipEventRecord(h->bwd_ev[4 + layer], st));
+            SIR_HIP_TRY(hipStreamWaitEvent(side, h->bwd_ev[4 + layer], 0));
+            rc = launch_dw(layer, side);
+            if (rc != SIR_OK) return rc;
+        } else if (!defer_dw) { rc = launch_dw(layer, st); if (rc != SIR_OK) return rc; }
         // gradient wrt the layer input: dgi [M][1536] x [W_ih; W_ih_reverse] [1536][in]
         SirProfScope prof(h, layer ? SIR_K_B_DX1 : SIR_K_B_DX0, st);
         float* dxin = layer ? p.dy0 : p.dx0;
@@ -598,12 +621,17 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         KCHECK();
     }
     }
+    if (dw_beside) {                                         // join: the GRU gradients are final on the caller's stream (the conv chain
+        SIR_HIP_TRY(hipEventRecord(h->bwd_ev[3], side));     // below does not depend on them, but the data-parallel caller reduces them next)
+        if (part == SIR_BWD_HEAD_GRU) SIR_HIP_TRY(hipStreamWaitEvent(st, h->bwd_ev[3], 0));
+    }
     if (part == SIR_BWD_HEAD_GRU) return SIR_OK;
-    if (two && !defer_dw) {                                  // SIR_BWD_CNN of the split form: the side stream starts behind the first half
+    if (fork_conv && !defer_dw) {                                  // SIR_BWD_CNN of the split form: the side stream starts behind the first half
         SIR_HIP_TRY(hipEventRecord(h->bwd_ev[0], st));
         SIR_HIP_TRY(hipStreamWaitEvent(side, h->bwd_ev[0], 0));
     }
 
+    hipStream_t cside = fork_conv ? side : st;               // stream of the convolution weight gradients
     // ---- conv3 block -------------------------------------------------------------------------
     if (!h->attr_wgrad) {
         SIR_HIP_TRY(hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<64, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -629,36 +657,36 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                                (const float*)p.dx0, scale + 96, shift + 96, smean + 96, sinv + 96, mdy + 96, mdyx + 96, p.dz3, B, 16,
                                d.wp2, 128, 8, d.wp3);
         }
-        if (two) {
+        if (fork_conv) {
             SIR_HIP_TRY(hipEventRecord(h->bwd_ev[1], st));
             SIR_HIP_TRY(hipStreamWaitEvent(side, h->bwd_ev[1], 0));
         }
         {
-            SirProfScope prof(h, SIR_K_B_WGRAD3, side);
+            SirProfScope prof(h, SIR_K_B_WGRAD3, cside);
             if ((sir_wgw_mask() & 2) && (size_t)B * 16 * d.wp2 * 128 * 4 < ((size_t)1 << 31)) {      // (32-bit buffer offsets)
                 // Winograd form: 16 products per tile and channel pair instead of 36 (wgrad_wino_bf16x6_kernel.h)
                 using Cfg3 = WgwCfg<64, 128>;
                 const int strips = wgrad_wino_strips(B, 16, d.wp2, Cfg3::TPS, Cfg3::groups, h->num_cus);
                 if (sir_f16_mask() & 32)
-                    hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<64, 128, true>), dim3(Cfg3::groups * strips), dim3(WGW_THREADS), Cfg3::lds_bytes, side,
+                    hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<64, 128, true>), dim3(Cfg3::groups * strips), dim3(WGW_THREADS), Cfg3::lds_bytes, cside,
                                        (const float*)p.dz3, (const float*)p.a2, p.slab, B, 16, d.wp2);
                 else
-                hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<64, 128>), dim3(Cfg3::groups * strips), dim3(WGW_THREADS), Cfg3::lds_bytes, side,
+                hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<64, 128>), dim3(Cfg3::groups * strips), dim3(WGW_THREADS), Cfg3::lds_bytes, cside,
                                    (const float*)p.dz3, (const float*)p.a2, p.slab, B, 16, d.wp2);
                 float* part = p.slab + (size_t)strips * 16 * 128 * 64;
-                hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((16 * 128 * 64 / 4 + 255) / 256), dim3(256), 0, side, (const float*)p.slab, strips,
+                hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((16 * 128 * 64 / 4 + 255) / 256), dim3(256), 0, cside, (const float*)p.slab, strips,
                                    16 * 128 * 64 / 4, part);
-                hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((128 * 64 + 255) / 256), dim3(256), 0, side, (const float*)part, 64, 128, g->conv_w[2], unscale);
+                hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((128 * 64 + 255) / 256), dim3(256), 0, cside, (const float*)part, 64, 128, g->conv_w[2], unscale);
             } else {
             const size_t ldsx = wgrad_x6_lds_bytes(64, 128, d.wp2);
             if (ldsx > 160 * 1024 || d.wp2 > wgrad_x6_max_w(128)) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
             const int nslab3 = d.wg3_blocks;                  // one slab per workgroup
-            hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<64, 128>), dim3(d.wg3_blocks), dim3(512), ldsx, side, (const float*)p.dz3,
+            hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<64, 128>), dim3(d.wg3_blocks), dim3(512), ldsx, cside, (const float*)p.dz3,
                                (const float*)p.a2, p.slab, 16, d.wp2, d.wg3_rb);
             float* part = p.slab + (size_t)nslab3 * 9 * 128 * 64;
-            hipLaunchKernelGGL(wgrad_reduce_partial_kernel, dim3((9 * 128 * 64 / 4 + 255) / 256, WGR_PARTS), dim3(256), 0, side,
+            hipLaunchKernelGGL(wgrad_reduce_partial_kernel, dim3((9 * 128 * 64 / 4 + 255) / 256, WGR_PARTS), dim3(256), 0, cside,
                                (const float*)p.slab, nslab3, 9 * 128 * 64 / 4, part);
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 128 * 64 + 255) / 256), dim3(256), 0, side, (const float*)part, WGR_PARTS, 64, 128,
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 128 * 64 + 255) / 256), dim3(256), 0, cside, (const float*)part, WGR_PARTS, 64, 128,
                                g->conv_w[2], unscale);
             }
         }
@@ -696,39 +724,39 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
                                (const float*)p.da2, scale + 32, shift + 32, smean + 32, sinv + 32, mdy + 32, mdyx + 32, p.dz2, B, 32,
                                d.wp1, 64, 16, d.wp2);
         }
-        if (two) {
+        if (fork_conv) {
             SIR_HIP_TRY(hipEventRecord(h->bwd_ev[2], st));
             SIR_HIP_TRY(hipStreamWaitEvent(side, h->bwd_ev[2], 0));
         }
         {
-            SirProfScope prof(h, SIR_K_B_WGRAD2, side);
+            SirProfScope prof(h, SIR_K_B_WGRAD2, cside);
             if ((sir_wgw_mask() & 1) && (size_t)B * 32 * d.wp1 * 64 * 4 < ((size_t)1 << 31)) {
                 using Cfg2 = WgwCfg<32, 64>;
                 const int strips = wgrad_wino_strips(B, 32, d.wp1, Cfg2::TPS, Cfg2::groups, h->num_cus);
                 if (sir_f16_mask() & 32)
-                    hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<32, 64, true>), dim3(Cfg2::groups * strips), dim3(WGW_THREADS), Cfg2::lds_bytes, side,
+                    hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<32, 64, true>), dim3(Cfg2::groups * strips), dim3(WGW_THREADS), Cfg2::lds_bytes, cside,
                                        (const float*)p.dz2, (const float*)p.a1, p.slab, B, 32, d.wp1);
                 else
-                hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<32, 64>), dim3(Cfg2::groups * strips), dim3(WGW_THREADS), Cfg2::lds_bytes, side,
+                hipLaunchKernelGGL((conv_wgrad_wino_bf16x6_kernel<32, 64>), dim3(Cfg2::groups * strips), dim3(WGW_THREADS), Cfg2::lds_bytes, cside,
                                    (const float*)p.dz2, (const float*)p.a1, p.slab, B, 32, d.wp1);
                 float* part = p.slab + (size_t)strips * 16 * 64 * 32;
-                hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((16 * 64 * 32 / 4 + 255) / 256), dim3(256), 0, side, (const float*)p.slab, strips,
+                hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((16 * 64 * 32 / 4 + 255) / 256), dim3(256), 0, cside, (const float*)p.slab, strips,
                                    16 * 64 * 32 / 4, part);
-                hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((64 * 32 + 255) / 256), dim3(256), 0, side, (const float*)part, 32, 64, g->conv_w[1], unscale);
+                hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((64 * 32 + 255) / 256), dim3(256), 0, cside, (const float*)part, 32, 64, g->conv_w[1], unscale);
             } else {
             const size_t ldsx = wgrad_x6_lds_bytes(32, 64, d.wp1);
             if (ldsx > 160 * 1024 || d.wp1 > wgrad_x6_max_w(64)) { sir_set_error("sir_model_train_bwd: t_frames too large for the weight-gradient tile"); return SIR_EUNSUPPORTED; }
             const int nslab2 = d.wg2_blocks;                  // one slab per workgroup (its four k-split waves add up in LDS)
-            hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<32, 64>), dim3(d.wg2_blocks), dim3(512), ldsx, side, (const float*)p.dz2,
+            hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<32, 64>), dim3(d.wg2_blocks), dim3(512), ldsx, cside, (const float*)p.dz2,
                                (const float*)p.a1, p.slab, 32, d.wp1, d.wg2_rb);
             float* part = p.slab + (size_t)nslab2 * 9 * 64 * 32;
-            hipLaunchKernelGGL(wgrad_reduce_partial_kernel, dim3((9 * 64 * 32 / 4 + 255) / 256, WGR_PARTS), dim3(256), 0, side,
+            hipLaunchKernelGGL(wgrad_reduce_partial_kernel, dim3((9 * 64 * 32 / 4 + 255) / 256, WGR_PARTS), dim3(256), 0, cside,
                                (const float*)p.slab, nslab2, 9 * 64 * 32 / 4, part);
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 32 + 255) / 256), dim3(256), 0, side, (const float*)part, WGR_PARTS, 32, 64,
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 32 + 255) / 256), dim3(256), 0, cside, (const float*)part, WGR_PARTS, 32, 64,
                                g->conv_w[1], unscale);
             }
         }
-        if (two) SIR_HIP_TRY(hipEventRecord(h->bwd_ev[3], side));     // (the side stream's last launch)
+        if (fork_conv) SIR_HIP_TRY(hipEventRecord(h->bwd_ev[3], side));     // (the side stream's last launch)
         {
             SirProfScope prof(h, SIR_K_B_DGRAD2, st);
             Wino2Geo geo2b;

@@ -93,7 +93,7 @@ struct sir_handle {
     // second stream of the training backward (SIR_BWD_STREAMS=1, model_train.hip): the off-chain weight-gradient launches; created on
     // first use.  ev: 0 fork behind the GRU part, 1 / 2 dz3 / dz2 ready, 3 join
     hipStream_t bwd_side;
-    hipEvent_t bwd_ev[4];
+    hipEvent_t bwd_ev[6];
 };
 
 // granule buffer + launch epoch for a cluster kernel launched on `st`; allocates / grows / zeroes the buffer when needed.
