@@ -171,7 +171,7 @@ int sir_wino2_mask();
 int sir_wgw_mask();      // SIR_WGW: convolution weight gradients in Winograd form: bit 0 = conv2, bit 1 = conv3 (default 3)
 int sir_tn2_mask();      // SIR_TN2: GRU backward GEMMs on the producer / consumer kernel: bit 0 = dW, bit 1 = dX on 128-row tiles, bit 2 = dX on 64-row tiles, bit 3 = a dX that would take 64-row tiles runs as two K halves on 128-row tiles instead (default 15)
 int sir_f16_mask();      // SIR_F16: stages on the f16x3 arithmetic (f16_split.h) instead of bf16x6: bit 0 = conv2 forward, bit 1 = conv3 forward (inference and training), bit 2 = conv3 data gradient, bit 3 = GRU backward GEMMs (dW, dX), bit 4 = conv2 data gradient (on the second-generation Winograd kernel: needs SIR_WINO2 bit 3), bit 5 = convolution weight gradients (default 63)
-int sir_bwd_streams();   // SIR_BWD_STREAMS: 1 = the backward's off-chain weight-gradient launches on a second, handle-owned stream (default 0)
+int sir_bwd_streams();   // SIR_BWD_STREAMS: which of the backward's weight-gradient launches run on a second, handle-owned stream (default 3; model_train.hip)
 
 int sir_check_hip(hipError_t e, const char* what);
 
