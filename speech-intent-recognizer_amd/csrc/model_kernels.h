@@ -12,6 +12,7 @@
 #include "sir_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float mk_f32x2 __attribute__((ext_vector_type(2)));
 
 #define SIR_BN_EPS 1e-5f
 
@@ -46,7 +47,7 @@ constexpr int C1_TR = 2 * C1_PROWS + 2, C1_TC = 2 * C1_PCOLS + 2;
 // Wave w = pooled row w of the 4 x 32 pooled-pixel block; per half (32 conv columns) two accumulators (the two conv rows
 // of the pooled row); 2x2 max = max of the two accumulators and of lanes j, j ^ 1.  Even lanes then store channel groups
 // 0, 1 and odd lanes groups 2, 3 of pooled pixel j / 2 (two float4 stores per lane).
-static __global__ __launch_bounds__(256) void conv1_mfma_bn_relu_pool_kernel(
+static __global__ __launch_bounds__(256, 4) void conv1_mfma_bn_relu_pool_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp) {
     // One block walks ALL row tiles of its column strip (grid = (column strips, 1, B)): weights / scale / shift are
@@ -107,12 +108,21 @@ static __global__ __launch_bounds__(256) void conv1_mfma_bn_relu_pool_kernel(
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s], b1, acc1, 0, 0, 0);
             }
             float m[16];
+            // BN of both conv rows as packed-f32 pairs (v_pk_fma_f32 / v_pk_max_f32: the same roundings, half the instructions -- the f32
+            // MFMAs above run on the SAME ALUs as the vector f32 ops, so every instruction of this epilogue adds to the kernel's time)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = fmaxf(fmaf(acc0[r], sc[r], sh[r]), fmaf(acc1[r], sc[r], sh[r]));
+            for (int r = 0; r < 16; r += 2) {
+                const mk_f32x2 s2 = {sc[r], sc[r + 1]}, h2 = {sh[r], sh[r + 1]};
+                const mk_f32x2 y0 = __builtin_elementwise_fma((mk_f32x2){acc0[r], acc0[r + 1]}, s2, h2);
+                const mk_f32x2 y1 = __builtin_elementwise_fma((mk_f32x2){acc1[r], acc1[r + 1]}, s2, h2);
+                // (scalar from here on: with the maximum taken on the pair, hipcc 7.2 expands the two DPP moves of its halves to TWO moves of
+                // the SAME half -- element r + 1 then pooled against element r's neighbour)
+                const float v0 = fmaxf(y0.x, y1.x), v1 = fmaxf(y0.y, y1.y);
                 // neighbouring pixel = lane ^ 1: quad_perm(1, 0, 3, 2) on the DPP path (no LDS round trip)
-                const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-                m[r] = fmaxf(fmaxf(v, nb), 0.0f);
+                const float nb0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v0), 0xB1, 0xF, 0xF, true));
+                const float nb1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v1), 0xB1, 0xF, 0xF, true));
+                m[r] = fmaxf(fmaxf(v0, nb0), 0.0f);
+                m[r + 1] = fmaxf(fmaxf(v1, nb1), 0.0f);
             }
             const int px = px0 + 16 * h + (j >> 1);
             const float4 lo = odd ? make_float4(m[8], m[9], m[10], m[11]) : make_float4(m[0], m[1], m[2], m[3]);
