@@ -39,7 +39,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_bwd_quad_kernel(
     const float* __restrict__ whh1, float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ bsum_i,
     float* __restrict__ bsum_h, int B, int S, unsigned long long* xbuf, unsigned int* status, unsigned epoch, int dbg,
     const uint4* __restrict__ wfrag0, const uint4* __restrict__ wfrag1) {
-    // wfrag0 / 1 (optional): prep_whh_bwd_quad_elem output for direction 0 / 1 (gru_frag_prep.h)
+    // wfrag0 / 1: prep_whh_bwd_quad_elem output for direction 0 / 1 (gru_frag_prep.h; required)
     extern __shared__ __attribute__((aligned(16))) unsigned char bqlds[];
     // workgroup -> (quarter, cluster) as in gru_quad_kernel: the four quarters of a cluster on ONE XCD
     const int nclusters = gridDim.x >> 2;
@@ -49,34 +49,25 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_bwd_quad_kernel(
     const int dir = cluster & 1, grp = cluster >> 1;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 15, kg = lane >> 4;
-    const float* __restrict__ whh = dir ? whh1 : whh0;       // [768][256]
     unsigned long long* xc = xbuf + (size_t)cluster * (2 * 4 * 4 * BQ_BLOCK);
 
     // ---- resident weights: A fragments (rows m = k index inside the tile, columns = own gate rows) -------------------
     // own gate row kk in [0, 192): gate kk >> 6, unit 64 q + (kk & 63) -> row (kk >> 6) * 256 + 64 q + (kk & 63) of W_hh
-    f16x8 wf[4][6][2];
-    const uint4* __restrict__ wfrag = dir ? wfrag1 : wfrag0;
-    if (wfrag) {
-        const uint4* wsrc = wfrag + (size_t)((q * 4 + wv) * 4 * 6 * 2) * 64 + lane;
+    f16x8 wf[4][6][2];                                       // (loaded straight into accumulation registers: gq_mfma_aw, gru_quad_kernel.h)
+    {
+        const uint4* wsrc = (dir ? wfrag1 : wfrag0) + (size_t)((q * 4 + wv) * 4 * 6 * 2) * 64 + lane;
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
             for (int s = 0; s < 6; ++s)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) wf[d][s][p] = __builtin_bit_cast(f16x8, wsrc[((d * 6 + s) * 2 + p) * 64]);
-    } else {
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int s = 0; s < 6; ++s) {
-                const int kk0 = 32 * s + 8 * kg;
-                const float* wcol = whh + (size_t)((kk0 >> 6) * 256 + q * GQ_UQ + (kk0 & 63)) * 256 + 64 * d + 16 * wv + n;
-                unsigned hh[4], ll[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) split2h_pair(wcol[(size_t)(2 * i) * 256], wcol[(size_t)(2 * i + 1) * 256], hh[i], ll[i]);
-                wf[d][s][0] = __builtin_bit_cast(f16x8, make_uint4(hh[0], hh[1], hh[2], hh[3]));
-                wf[d][s][1] = __builtin_bit_cast(f16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
-            }
+                for (int p = 0; p < 2; ++p)
+#ifdef SIR_GQ_BUILTIN_MFMA
+                    wf[d][s][p] = __builtin_bit_cast(f16x8, wsrc[((d * 6 + s) * 2 + p) * 64]);
+#else
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(wf[d][s][p]) : "v"(wsrc + ((d * 6 + s) * 2 + p) * 64));
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
     // ---- two thread roles ------------------------------------------------------------------------------------------------
@@ -176,15 +167,17 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_bwd_quad_kernel(
                     for (int p = 0; p < 2; ++p)
                         gf[s][p] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(pb + p * BQ_PLANEB + frag_off + s * 64));
                 __builtin_amdgcn_sched_barrier(0);
+                gq_mfma_enter(acc, accx);
 #pragma unroll
                 for (int s = 0; s < 6; ++s) {
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) accx[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[d][s][1], gf[s][0], accx[d], 0, 0, 0);
+                    for (int d = 0; d < 4; ++d) gq_mfma_aw(accx[d], wf[d][s][1], gf[s][0]);
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) accx[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[d][s][0], gf[s][1], accx[d], 0, 0, 0);
+                    for (int d = 0; d < 4; ++d) gq_mfma_aw(accx[d], wf[d][s][0], gf[s][1]);
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[d][s][0], gf[s][0], acc[d], 0, 0, 0);
+                    for (int d = 0; d < 4; ++d) gq_mfma_aw(acc[d], wf[d][s][0], gf[s][0]);
                 }
+                gq_mfma_fence(acc, accx);
 #pragma unroll
                 for (int d = 0; d < 4; ++d)
 #pragma unroll

@@ -12,6 +12,7 @@ int sir_launch_gru_quad(sir_handle* h, hipStream_t st, bool save, const float* g
         h->attr_gru_quad = true;
     }
     if (S >= 511) { sir_set_error("gru_quad: %d steps exceed the 9-bit step field of the granule tag", S); return SIR_EUNSUPPORTED; }
+    if (!wfrag0 || !wfrag1) { sir_set_error("gru_quad: the prepared W_hh fragments are required (sir_prep_whh_quad / train_prep_kernel)"); return SIR_EINVAL; }
     const int clusters = ((B + GQ_NU - 1) / GQ_NU) * 2;
     unsigned epoch = 0;
     void* xbuf = nullptr;
@@ -47,6 +48,7 @@ int sir_launch_gru_bwd_quad(sir_handle* h, hipStream_t st, const float* dy, cons
         h->attr_gru_bwd_quad = true;
     }
     if (S >= 65535) { sir_set_error("gru_bwd_quad: %d steps exceed the 16-bit step field of the granule tag", S); return SIR_EUNSUPPORTED; }
+    if (!wfrag0 || !wfrag1) { sir_set_error("gru_bwd_quad: the prepared W_hh fragments are required (train_prep_kernel)"); return SIR_EINVAL; }
     const int clusters = ((B + GQ_NU - 1) / GQ_NU) * 2;
     unsigned epoch = 0;
     void* xbuf = nullptr;

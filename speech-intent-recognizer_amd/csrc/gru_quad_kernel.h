@@ -43,6 +43,38 @@ constexpr size_t GQ_XBUF_PER_CLUSTER = (size_t)2 * 4 * GQ_NU * GQ_UQ * 8;   // [
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+// One v_mfma_f32_16x16x32_f16 whose A operand (a resident W_hh fragment) is taken from an ACCUMULATION register.  The recurrence kernels
+// keep 192 registers of weight fragments for the whole sequence; left to the register allocator they overflow the 256 architectural
+// VGPRs and it parks part of the working set in AGPRs, copying it back and forth every step (64 v_accvgpr_read + 48 v_accvgpr_write
+// per step in the forward kernel, 121 + 103 in the BPTT kernel: ~0.2-0.35 us of a 2.7-4 us step).  gfx90a+ matrix instructions read
+// A / B from AGPRs directly, so the fragments are pinned there by the operand constraint and nothing is copied.  hipcc cannot see an
+// MFMA inside inline asm: the wait states it would insert between the matrix results and their first vector use are added by hand
+// (gq_mfma_fence: 16 idle cycles cover the 4-pass result latency; gq_mfma_enter: 4 in front of the block cover vector writes of its operands).
+__device__ __forceinline__ void gq_mfma_aw(f32x4_t& acc, const f16x8& w, const f16x8& h) {
+#ifdef SIR_GQ_BUILTIN_MFMA                                   // A/B build only (devtools/gpu_r4q.sh): compiler-managed registers
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, h, acc, 0, 0, 0);
+#else
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(h));
+#endif
+}
+__device__ __forceinline__ void gq_mfma_wa(f32x4_t& acc, const f16x8& h, const f16x8& w) {        // the fragment as the B operand
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(h), "a"(w));
+}
+// wait states in front of / behind a block of inline-asm MFMAs, TIED to the accumulators by in-out operands so that neither the
+// accumulators' initialisation nor their first vector use can be scheduled to the wrong side of the idle cycles
+__device__ __forceinline__ void gq_mfma_enter(f32x4_t (&a)[3], f32x4_t (&b)[3]) {
+    asm volatile("s_nop 3" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
+}
+__device__ __forceinline__ void gq_mfma_fence(f32x4_t (&a)[3], f32x4_t (&b)[3]) {
+    asm volatile("s_nop 15" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
+}
+__device__ __forceinline__ void gq_mfma_enter(f32x4_t (&a)[4], f32x4_t (&b)[4]) {
+    asm volatile("s_nop 3" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+__device__ __forceinline__ void gq_mfma_fence(f32x4_t (&a)[4], f32x4_t (&b)[4]) {
+    asm volatile("s_nop 15" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+
 // gate non-linearities from the hardware exp2 / rcp (1 ulp each) instead of the libm expf / tanhf / IEEE division:
 // this kernel evaluates 12 of them per lane and step on ONE wave per SIMD, where the ~110-instruction libm
 // forms cost ~1 us per step.  Absolute error ~1e-7 (sigmoid) / ~2e-7 (tanh), far inside the 2e-5 logit tolerance.
@@ -71,7 +103,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ y, int B, int S,
     float* __restrict__ gates, unsigned long long* xbuf, unsigned int* status, int dbg, unsigned epoch, unsigned short* __restrict__ yplanes,
     const uint4* __restrict__ wfrag0, const uint4* __restrict__ wfrag1) {
-    // wfrag0/1 (optional): prep_whh_quad_kernel output for direction 0 / 1
+    // wfrag0/1: prep_whh_quad_elem output for direction 0 / 1 (required)
     // yplanes (optional): f16x2 planes [2][B * S][512] (f16_split.h) of y, the A operand of the next layer's input projection
     // dbg (timing experiments only, results invalid): bit 0 = do not wait for the granules, bit 1 = skip the MFMAs,
     // bit 2 = skip publish + receive; fault injection for the status-word test: bit 3 = quarter 3 never publishes (its
@@ -92,36 +124,26 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     const int b = grp * GQ_NU + n;
     const bool bvalid = b < B;
     const int u0 = q * GQ_UQ + wv * 16 + kg * 4;             // first of this lane's 4 hidden units (D rows 4 kg .. 4 kg + 3)
-    const float* __restrict__ whh = dir ? whh1 : whh0;       // [768][256]
     const float* __restrict__ bhh = dir ? bhh1 : bhh0;
     unsigned long long* xc = xbuf + (size_t)cluster * (2 * 4 * GQ_NU * GQ_UQ);
 
     // ---- resident weights: A fragments of the three gate tiles, f16x2 planes ----------------------------
+    // (loaded straight INTO accumulation registers, where gq_mfma_aw reads them: see its comment; the launcher insists on prepared fragments)
     f16x8 wf[3][8][GQ_NPL];
-    const uint4* __restrict__ wfrag = dir ? wfrag1 : wfrag0;
-    if (wfrag) {
-        const uint4* wsrc = wfrag + (size_t)((q * 4 + wv) * 3 * 8 * GQ_NPL) * 64 + lane;
+    {
+        const uint4* wsrc = (dir ? wfrag1 : wfrag0) + (size_t)((q * 4 + wv) * 3 * 8 * GQ_NPL) * 64 + lane;
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
             for (int s = 0; s < 8; ++s)
 #pragma unroll
-                for (int p = 0; p < GQ_NPL; ++p) wf[g][s][p] = __builtin_bit_cast(f16x8, wsrc[((g * 8 + s) * GQ_NPL + p) * 64]);
-    } else {
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        const float* wrow = whh + (size_t)(g * 256 + q * GQ_UQ + wv * 16 + n) * 256 + kg * 8;   // A row = lane & 15
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const float4 v0 = *reinterpret_cast<const float4*>(wrow + s * 32);
-            const float4 v1 = *reinterpret_cast<const float4*>(wrow + s * 32 + 4);
-            uint2 h0, l0, h1, l1;
-            split2h_quad(v0, h0, l0);
-            split2h_quad(v1, h1, l1);
-            wf[g][s][0] = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
-            wf[g][s][1] = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
-        }
-    }
+                for (int p = 0; p < GQ_NPL; ++p)
+#ifdef SIR_GQ_BUILTIN_MFMA
+                    wf[g][s][p] = __builtin_bit_cast(f16x8, wsrc[((g * 8 + s) * GQ_NPL + p) * 64]);
+#else
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(wf[g][s][p]) : "v"(wsrc + ((g * 8 + s) * GQ_NPL + p) * 64));
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     float4 bh[3];
 #pragma unroll
@@ -169,15 +191,17 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
             for (int p = 0; p < GQ_NPL; ++p)
                 hf[s][p] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(hb + p * GQ_PLANEB + frag_off + s * 64));
         __builtin_amdgcn_sched_barrier(0);
+        gq_mfma_enter(acc, accx);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) accx[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[g][s][1], hf[s][0], accx[g], 0, 0, 0);
+            for (int g = 0; g < 3; ++g) gq_mfma_aw(accx[g], wf[g][s][1], hf[s][0]);
 #pragma unroll
-            for (int g = 0; g < 3; ++g) accx[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[g][s][0], hf[s][1], accx[g], 0, 0, 0);
+            for (int g = 0; g < 3; ++g) gq_mfma_aw(accx[g], wf[g][s][0], hf[s][1]);
 #pragma unroll
-            for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[g][s][0], hf[s][0], acc[g], 0, 0, 0);
+            for (int g = 0; g < 3; ++g) gq_mfma_aw(acc[g], wf[g][s][0], hf[s][0]);
         }
+        gq_mfma_fence(acc, accx);
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
