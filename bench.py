@@ -832,7 +832,8 @@ def main():
                     "ms_per_step": round(ms, 4), "steps": args.train_steps, "timed_regions": region_stats(tt, args.train_steps),
                     "workload": "waveform batch 256/GPU -> HIP features" +
                                 (" with fused time-shift + noise + SpecAugment masks" if augment else "") +
-                                " -> forward/backward (dropout 0.5, batch-stat BN) -> Adam(lr 5e-5, wd 1e-4)" +
+                                " -> forward/backward (dropout 0.5, batch-stat BN; the backward's weight-gradient launches on a second, "
+                                "library-owned stream: SIR_BWD_STREAMS) -> Adam(lr 5e-5, wd 1e-4)" +
                                 (", RCCL all-reduce of 13 MB grads in two overlapped buckets" if world > 1 else ""),
                     "model_flops_per_utt_fwd_bwd": TRAIN_FLOPS_PER_UTT,
                     "roofline": dict(mfma_roofline(tdom, td_ms[tdom], td_cnt[tdom], batch),
@@ -840,7 +841,9 @@ def main():
                                                  "peak": round(PEAK_F16X3_TFLOPS, 1), "unit": "TFLOP/s",
                                                  "frac": round(step_tf / PEAK_F16X3_TFLOPS, 4),
                                                  "note": "1.2019 GFLOP/utt (fwd + dgrad + wgrad convention) x 256 / per-GPU step time"}),
-                    "kernels_avg_ms": {k: round(v, 5) for k, v in tk_ms.items() if v > 0.0}}
+                    "kernels_avg_ms": {k: round(v, 5) for k, v in tk_ms.items() if v > 0.0},
+                    "kernels_avg_ms_note": "HIP-event times of an untimed pass in which the backward stays on ONE stream (un-overlapped "
+                                           "kernel times: their sum exceeds ms_per_step, whose timed regions run the two-stream form)"}
             if rank == 0:
                 log(f"train leg (augment={augment}): {info['value']} utt/s")
             return info

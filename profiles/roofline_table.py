@@ -54,6 +54,7 @@ ROWS = [
     ("conv_wgrad_bf16x6_kernel<32, 64>", "bwd conv2 wgrad", "train", "mfma6", F["bwd_conv2_wgrad"] * B, A1 + Z2),
     ("conv_wgrad_bf16x6_kernel<64, 128>", "bwd conv3 wgrad", "train", "mfma6", F["bwd_conv3_wgrad"] * B, A2 + Z3),
     ("gru_quad_kernel<true>", "train GRU recurrence (l0, l1)", "train", "mfma6", F["train_gru_l0"] * B, GI + Y + B * S * 2048 * 4),
+    ("gru_bwd_quad_kernel", "BPTT recurrence on the matrix cores (l1, l0)", "train", "mfma6", F["bwd_gru_l0"] * B, B * S * (2048 + 512 + 512 + 1536 + 1536) * 4),
     ("gru_bwd_pair_k4_kernel", "BPTT recurrence, four-k layout (l1, l0)", "train", "mfma6", F["bwd_gru_l0"] * B, B * S * (2048 + 512 + 512 + 1536 + 1536) * 4),
     ("gru_bwd_pair_kernel", "BPTT recurrence (l1, l0)", "train", "mfma6", F["bwd_gru_l0"] * B, B * S * (2048 + 512 + 512 + 1536 + 1536) * 4),
     ("gru_bwd_quad_kernel", "BPTT recurrence, MFMA cluster (l1, l0)", "train", "mfma6", F["bwd_gru_l0"] * B, B * S * (2048 + 512 + 512 + 1536 + 1536) * 4),
