@@ -7,8 +7,10 @@ int sir_launch_gru_quad(sir_handle* h, hipStream_t st, bool save, const float* g
                         const float* bhh1, float* y, int B, int S, float* gates, unsigned short* yplanes, const void* wfrag0,
                         const void* wfrag1) {
     if (!h->attr_gru_quad) {
-        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_quad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GQ_LDS_BYTES));
-        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_quad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GQ_LDS_BYTES));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_quad_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GQ_LDS_BYTES));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_quad_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GQ_LDS_BYTES));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_quad_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GQ_LDS_BYTES));
+        SIR_HIP_TRY(hipFuncSetAttribute((const void*)gru_quad_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GQ_LDS_BYTES));
         h->attr_gru_quad = true;
     }
     if (S >= 511) { sir_set_error("gru_quad: %d steps exceed the 9-bit step field of the granule tag", S); return SIR_EUNSUPPORTED; }
@@ -24,12 +26,16 @@ int sir_launch_gru_quad(sir_handle* h, hipStream_t st, bool save, const float* g
     static const int dbg0 = getenv("SIR_GRU_DBG") ? atoi(getenv("SIR_GRU_DBG")) : 0;
     static const int delay = getenv("SIR_GQ_DELAY") ? atoi(getenv("SIR_GQ_DELAY")) & 31 : GQ_POLL_DELAY;      // A/B of the first poll's delay
     const int dbg = (dbg0 & ~(31 << 8)) | ((((dbg0 >> 8) & 31) ? ((dbg0 >> 8) & 31) : delay) << 8);
-    if (save)
-        hipLaunchKernelGGL(gru_quad_kernel<true>, grid, dim3(GQ_THREADS), GQ_LDS_BYTES, st, gi, whh0, whh1, bhh0, bhh1, y, B, S, gates,
-                           (unsigned long long*)xbuf, h->status, dbg, epoch, yplanes, (const uint4*)wfrag0, (const uint4*)wfrag1);
-    else
-        hipLaunchKernelGGL(gru_quad_kernel<false>, grid, dim3(GQ_THREADS), GQ_LDS_BYTES, st, gi, whh0, whh1, bhh0, bhh1, y, B, S, gates,
-                           (unsigned long long*)xbuf, h->status, dbg, epoch, yplanes, (const uint4*)wfrag0, (const uint4*)wfrag1);
+    // SIR_GQ_ROLES (default 1): gate arithmetic and global accesses in the coalesced thread layout -- bit 0: the gate-saving (training)
+    // form, whose five 16-byte stores per lane and step were fully exposed (layer 0: 79.5 -> 71.4 us); bit 1: the inference form, where
+    // the extra barrier costs more than its one to three stores (71.6 -> 74.7 us: off).  profiles/r04/ab_gq_roles.txt
+    static const int roles = getenv("SIR_GQ_ROLES") ? atoi(getenv("SIR_GQ_ROLES")) : 1;
+    typedef void (*kern_t)(const float*, const float*, const float*, const float*, const float*, float*, int, int, float*, unsigned long long*,
+                           unsigned int*, int, unsigned, unsigned short*, const uint4*, const uint4*);
+    const kern_t kern = save ? ((roles & 1) ? gru_quad_kernel<true, true> : gru_quad_kernel<true, false>)
+                             : ((roles & 2) ? gru_quad_kernel<false, true> : gru_quad_kernel<false, false>);
+    hipLaunchKernelGGL(kern, grid, dim3(GQ_THREADS), GQ_LDS_BYTES, st, gi, whh0, whh1, bhh0, bhh1, y, B, S, gates,
+                       (unsigned long long*)xbuf, h->status, dbg, epoch, yplanes, (const uint4*)wfrag0, (const uint4*)wfrag1);
     SIR_HIP_TRY(hipGetLastError());
     return SIR_OK;
 }

@@ -36,7 +36,9 @@ constexpr int GQ_ROWB = 256 * 2 + 32;     // bytes per utterance row of one h pl
 constexpr int GQ_PLANEB = GQ_NU * GQ_ROWB;
 constexpr int GQ_NPL = 2;                 // h planes: hi, scaled residual
 constexpr int GQ_BUFB = GQ_NPL * GQ_PLANEB;    // one parity buffer: 17,408 B
-constexpr size_t GQ_LDS_BYTES = 2 * (size_t)GQ_BUFB;
+constexpr size_t GQ_LDS_PLANES = 2 * (size_t)GQ_BUFB;
+constexpr int GQ_TROW = 64 + 4;                              // floats per (utterance, gate) row of the layout-crossing image
+constexpr size_t GQ_LDS_BYTES = GQ_LDS_PLANES + (size_t)GQ_NU * 3 * GQ_TROW * 4;      // (+ 13 KB, used by the ROLES form)
 constexpr unsigned GQ_SPIN_LIMIT = 1u << 22;
 constexpr int GQ_POLL_DELAY = 8;           // default (16 before the f16x3 step got shorter: profiles/r04/ab_gq_delay.txt), x 64 cycles between the granule stores and the first poll round (see the poll loop); passed in dbg bits 8-12
 constexpr size_t GQ_XBUF_PER_CLUSTER = (size_t)2 * 4 * GQ_NU * GQ_UQ * 8;   // [parity][quarter][wave][store 0 | 1][lane][2] granules (producer-thread order)
@@ -97,7 +99,11 @@ static __global__ __launch_bounds__(256) void prep_whh_quad_kernel(const float* 
 //        this buffer, 9-bit step + 1}: a granule of an earlier launch never matches, so the buffer is zeroed only when it is
 //        new or grows (sir_xbuf_epoch), not before every launch
 // status set to 1 if a spin times out (results are then invalid; cannot happen while a cluster is co-resident)
-template <bool SAVE>
+// ROLES: two thread roles as in gru_bwd_quad_kernel.h -- the MFMA result layout (lane = utterance lane & 15, units 16 wave + 4 (lane >> 4) + j)
+// only for the product; the gate arithmetic and everything that touches global memory (gi loads, y / gate / plane stores) in a GATE layout
+// (utterance 4 wave + lane / 16, units 4 (lane & 15) + j): 256 contiguous bytes per 16 lanes instead of 64 separate 16-byte requests per
+// instruction.  The pre-activations cross over through a 13 KB LDS image and one more barrier per step.
+template <bool SAVE, bool ROLES = false>
 __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     const float* __restrict__ gi, const float* __restrict__ whh0, const float* __restrict__ whh1,
     const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ y, int B, int S,
@@ -121,9 +127,13 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
     const int dir = cluster & 1, grp = cluster >> 1;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 15, kg = lane >> 4;                 // MFMA column (utterance) / k-group and D row group
-    const int b = grp * GQ_NU + n;
+    // gate role (== the MFMA result layout unless ROLES): utterance gutt of the cluster, units gul0 .. gul0 + 3 of the quarter
+    const int gutt = ROLES ? 4 * wv + (lane >> 4) : n;
+    const int gul0 = ROLES ? 4 * (lane & 15) : wv * 16 + kg * 4;
+    const int b = grp * GQ_NU + gutt;
     const bool bvalid = b < B;
-    const int u0 = q * GQ_UQ + wv * 16 + kg * 4;             // first of this lane's 4 hidden units (D rows 4 kg .. 4 kg + 3)
+    const int u0 = q * GQ_UQ + gul0;                         // first of this thread's 4 hidden units
+    float* const tl = reinterpret_cast<float*>(qlds + GQ_LDS_PLANES);      // ROLES: [16 utterances][3 gates][GQ_TROW] pre-activations
     const float* __restrict__ bhh = dir ? bhh1 : bhh0;
     unsigned long long* xc = xbuf + (size_t)cluster * (2 * 4 * GQ_NU * GQ_UQ);
 
@@ -207,6 +217,17 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[g][j] = fmaf(accx[g][j], H3_LO_INV, acc[g][j]);
         }
+        if constexpr (ROLES) {                               // matrix layout -> gate layout (the image was last read before the step's closing barrier)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                *reinterpret_cast<float4*>(tl + (n * 3 + g) * GQ_TROW + wv * 16 + kg * 4) = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const float4 v = *reinterpret_cast<const float4*>(tl + (gutt * 3 + g) * GQ_TROW + gul0);
+                acc[g][0] = v.x; acc[g][1] = v.y; acc[g][2] = v.z; acc[g][3] = v.w;
+            }
+        }
 
         // ---- gates for 4 units x 1 utterance ------------------------------------------------------------
         float hn4[4], r4[4], z4[4], n4[4], hh4[4];
@@ -230,7 +251,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
         uint2 ph, pl;
         split2h_quad(hprev, ph, pl);
         {
-            unsigned char* d = hnb + n * GQ_ROWB + u0 * 2;
+            unsigned char* d = hnb + gutt * GQ_ROWB + u0 * 2;
             *reinterpret_cast<uint2*>(d) = ph;
             *reinterpret_cast<uint2*>(d + GQ_PLANEB) = pl;
         }
@@ -306,7 +327,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gru_quad_kernel(
                 rh.y = (unsigned)((v[qi][2] >> 32) & 0xFFFFu) | ((unsigned)((v[qi][3] >> 32) & 0xFFFFu) << 16);
                 rl.x = (unsigned)((v[qi][0] >> 16) & 0xFFFFu) | ((unsigned)((v[qi][1] >> 16) & 0xFFFFu) << 16);
                 rl.y = (unsigned)((v[qi][2] >> 16) & 0xFFFFu) | ((unsigned)((v[qi][3] >> 16) & 0xFFFFu) << 16);
-                unsigned char* d = hnb + n * GQ_ROWB + (qs * GQ_UQ + (u0 - q * GQ_UQ)) * 2;
+                unsigned char* d = hnb + gutt * GQ_ROWB + (qs * GQ_UQ + gul0) * 2;
                 *reinterpret_cast<uint2*>(d) = rh;
                 *reinterpret_cast<uint2*>(d + GQ_PLANEB) = rl;
             }
