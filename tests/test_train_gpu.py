@@ -667,3 +667,38 @@ def test_gru_timeout_is_reported_not_swallowed(tmp_path):
     env = dict(os.environ, SIR_GRU_DBG="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RAISED" not in r.stdout, (r.stdout, r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("bsz", [256, 21])
+def test_two_stream_backward_is_bit_identical_to_one_stream(sd, bsz):
+    """The backward's weight-gradient launches run on a second, library-owned stream (SIR_BWD_STREAMS, csrc/model_train.hip); while every
+    kernel is timed (sir_profile_enable mode 1) the same call keeps everything on the caller's stream.  No reduction depends on the
+    order in which the two streams finish, so every parameter gradient must be BIT-identical between the two forms, run after run (a
+    missing fork / join edge or a shared slab shows up here as a difference)."""
+    import ctypes as C
+    from sir_amd import _native
+    from sir_amd.featurizer import get_featurizer
+    lib, h = _native.lib(), get_featurizer().handle
+    x = cases.varied_features(bsz, 200, seed=900 + bsz).to(DEV)
+    y = synth.synth_labels(bsz, 31, seed=901 + bsz).to(DEV)
+    m = _model(sd)                                   # dropout 0: the mask is keyed on a step counter
+
+    def grads():
+        m.zero_grad(set_to_none=True)
+        loss = train_ops.fused_cross_entropy(m(x), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    two = [grads() for _ in range(3)]
+    _native.check(lib.sir_profile_enable(h, 1, -1), "sir_profile_enable")
+    try:
+        one = grads()
+    finally:
+        nk = lib.sir_profile_kernel_count()
+        ms, cnt = (C.c_double * nk)(), (C.c_int64 * nk)()
+        lib.sir_profile_collect(h, ms, cnt, nk)
+        _native.check(lib.sir_profile_enable(h, 0, -1), "sir_profile_enable")
+    for n in one:
+        for k, g in enumerate(two):
+            assert torch.equal(g[n], one[n]), (n, k, (g[n] - one[n]).abs().max().item())
