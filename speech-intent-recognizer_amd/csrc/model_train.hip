@@ -2,6 +2,7 @@
 // activations (sir_model_train_fwd), cross-entropy (sir_ce_loss), full backward
 // (sir_model_train_bwd) and multi-tensor Adam (sir_adam_step).  Replaces the body of
 // train_epoch (scripts/train.py:90-107: forward, criterion, loss.backward(), optimizer.step()).
+#include <cstdlib>
 #include "bf16x6_kernels.h"
 #include "f16x3_kernels.h"
 #include "train_kernels.h"
@@ -562,6 +563,15 @@ extern "C" int sir_model_train_bwd_part(sir_handle* h, const sir_model_weights* 
         if (dw_beside) {                                     // (layer 0's GEMM queues behind layer 1's on the side stream: they share the slabs)
             SIR_HIP_TRY(hipEventRecord(h->bwd_ev[4 + layer], st));
             SIR_HIP_TRY(hipStreamWaitEvent(side, h->bwd_ev[4 + layer], 0));
+            // Layer 0's saved gates and outputs (65 MB) were written early in the forward and have left the 256 MB last-level cache by now;
+            // layer 1's are still there, and layer 0's BPTT -- a latency chain whose polls share the L2 channels with its input misses --
+            // pays 16-26 us for the difference (profiles/r04/ab_bptt.txt).  A read-and-drop pass on the side stream, beside layer 1's dX on
+            // the caller's, brings them back: step -28 .. -40 us (SIR_BPTT_TOUCH=0 turns it off).  The same for the raw conv outputs ahead
+            // of the BatchNorm backward was measured and LOSES (those kernels are bandwidth-bound: the reads are only moved earlier).
+            static const bool touch = !getenv("SIR_BPTT_TOUCH") || atoi(getenv("SIR_BPTT_TOUCH")) != 0;
+            if (touch && layer == 1)
+                hipLaunchKernelGGL(cache_touch_kernel, dim3(256), dim3(256), 0, side, (const float4*)p.g0, (size_t)M * 2048 / 4, (const float4*)p.y0,
+                                   (size_t)M * 512 / 4, p.small);
             rc = launch_dw(layer, side);
             if (rc != SIR_OK) return rc;
         } else if (!defer_dw) { rc = launch_dw(layer, st); if (rc != SIR_OK) return rc; }

@@ -558,6 +558,17 @@ static __global__ __launch_bounds__(256) void train_prep_kernel(PrepJobs jobs) {
     }
 }
 
+// Reads two buffers and keeps nothing: a software prefetch into the last-level cache, launched on the backward's side stream (model_train.hip:
+// layer 0's saved gates and outputs ahead of its BPTT)
+static __global__ __launch_bounds__(256) void cache_touch_kernel(const float4* __restrict__ a, size_t na, const float4* __restrict__ b, size_t nb,
+                                                                  float* __restrict__ sink) {
+    float acc = 0.0f;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < na; i += stride) { const float4 v = a[i]; acc += v.x + v.y + v.z + v.w; }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += stride) { const float4 v = b[i]; acc += v.x + v.y + v.z + v.w; }
+    if (acc == 123456.789f) sink[0] = acc;               // (never true in practice; keeps the loads)
+}
+
 // out_j[i] = sum_z slabs_j[z][i] for up to four jobs (blockIdx.y) with a common slab count; slab stride = n_j
 struct SlabJobs { const float* src[4]; float* out[4]; size_t n[4]; };
 static __global__ void slab_reduce_jobs_kernel(SlabJobs jobs, int nslab, float unscale) {
