@@ -86,7 +86,7 @@ KERNEL_SYMBOL = {
     "feat_frames": "feat_utt_kernel<float,false>", "conv1_bn_relu_pool": "conv1_mfma_bn_relu_pool_kernel",
     "conv2_mfma_bn_relu_pool": "conv3x3_wino2_bf16x6_kernel<32,64,0,F16>", "conv3_mfma_bn_relu_pool": "conv3x3_wino2_bf16x6_kernel<64,128,1,F16>",
     "gemm_ih_l0": "gemm_nt_f16x3_kernel", "gemm_ih_l1": "gemm_nt_f16x3_kernel",
-    "gru_recurrence_l0": "gru_quad_kernel<false>", "gru_recurrence_l1": "gru_quad_kernel<false>",
+    "gru_recurrence_l0": "gru_quad_kernel<false, false>", "gru_recurrence_l1": "gru_quad_kernel<false, false>",
     "attention_pool_fc_argmax": "attention_pool_kernel",
 }
 FWD_FLOPS_PER_UTT = 400646144

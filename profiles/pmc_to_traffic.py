@@ -27,7 +27,7 @@ NAME_MAP = [
     ("conv3x3_bf16x6_ns_kernel<64, 32", "bwd_conv2_dgrad"), ("conv3x3_bf16x6_ns_kernel<128, 64", "bwd_conv3_dgrad"),
     ("conv_wgrad_wino_bf16x6_kernel<32, 64", "bwd_conv2_wgrad"), ("conv_wgrad_wino_bf16x6_kernel<64, 128", "bwd_conv3_wgrad"),
     ("conv_wgrad_bf16x6_kernel<32, 64>", "bwd_conv2_wgrad"), ("conv_wgrad_bf16x6_kernel<64, 128>", "bwd_conv3_wgrad"),
-    ("gru_quad_kernel<true>", "train_gru"), ("gru_bwd_pair_kernel", "bwd_gru"), ("gru_bwd_pair_k4_kernel", "bwd_gru"), ("gru_bwd_quad_kernel", "bwd_gru"),
+    ("gru_quad_kernel<true", "train_gru"), ("gru_bwd_pair_kernel", "bwd_gru"), ("gru_bwd_pair_k4_kernel", "bwd_gru"), ("gru_bwd_quad_kernel", "bwd_gru"),
     ("gemm_tn2_bf16x6_kernel<true", "bwd_gru_dw"), ("gemm_tn2_bf16x6_kernel<false", "bwd_gru_dx"),
     ("gemm_tn_bf16x6_kernel<true", "bwd_gru_dw"), ("gemm_tn_bf16x6_kernel<false", "bwd_gru_dx"),
     ("bn_bwd_dz_kernel<false>", "bwd_bn2_dz"), ("bn_bwd_dz_kernel<true>", "bwd_bn3_dz"), ("conv1_bwd_kernel", "bwd_conv1"),

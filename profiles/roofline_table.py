@@ -53,7 +53,7 @@ ROWS = [
     ("conv_wgrad_wino_bf16x6_kernel<64, 128", "bwd conv3 wgrad (Winograd)", "train", "mfma6", F["bwd_conv3_wgrad"] * B, A2 + Z3),
     ("conv_wgrad_bf16x6_kernel<32, 64>", "bwd conv2 wgrad", "train", "mfma6", F["bwd_conv2_wgrad"] * B, A1 + Z2),
     ("conv_wgrad_bf16x6_kernel<64, 128>", "bwd conv3 wgrad", "train", "mfma6", F["bwd_conv3_wgrad"] * B, A2 + Z3),
-    ("gru_quad_kernel<true>", "train GRU recurrence (l0, l1)", "train", "mfma6", F["train_gru_l0"] * B, GI + Y + B * S * 2048 * 4),
+    ("gru_quad_kernel<true", "train GRU recurrence (l0, l1)", "train", "mfma6", F["train_gru_l0"] * B, GI + Y + B * S * 2048 * 4),
     ("gru_bwd_quad_kernel", "BPTT recurrence on the matrix cores (l1, l0)", "train", "mfma6", F["bwd_gru_l0"] * B, B * S * (2048 + 512 + 512 + 1536 + 1536) * 4),
     ("gru_bwd_pair_k4_kernel", "BPTT recurrence, four-k layout (l1, l0)", "train", "mfma6", F["bwd_gru_l0"] * B, B * S * (2048 + 512 + 512 + 1536 + 1536) * 4),
     ("gru_bwd_pair_kernel", "BPTT recurrence (l1, l0)", "train", "mfma6", F["bwd_gru_l0"] * B, B * S * (2048 + 512 + 512 + 1536 + 1536) * 4),
@@ -88,7 +88,7 @@ ROWS = [
     ("conv3x3_wino_bf16x6_kernel<64, 128", "conv3 + BN + ReLU + pool (Winograd)", "infer", "mfma6", F["conv3_mfma_bn_relu_pool"] * B, A2 + X0 + X0 * 3 // 2),
     ("conv3x3_bf16x6_ns_kernel<32, 64", "conv2 + BN + ReLU + pool (direct)", "infer", "mfma6", F["conv2_mfma_bn_relu_pool"] * B, A1 + A2),
     ("conv3x3_bf16x6_ns_kernel<64, 128", "conv3 + BN + ReLU + pool (direct)", "infer", "mfma6", F["conv3_mfma_bn_relu_pool"] * B, A2 + X0 + X0 * 3 // 2),
-    ("gru_quad_kernel<false>", "GRU recurrence (l0, l1)", "infer", "mfma6", F["gru_recurrence_l0"] * B,
+    ("gru_quad_kernel<false", "GRU recurrence (l0, l1)", "infer", "mfma6", F["gru_recurrence_l0"] * B,
      (bench.GRU_ALGO_BYTES["gru_recurrence_l0"] + bench.GRU_ALGO_BYTES["gru_recurrence_l1"]) // 2),
     ("attention_pool_kernel", "attention pool + fc + argmax", "infer", "hbm", None, Y),
 ]
