@@ -1,0 +1,18 @@
+#!/bin/bash
+# round 4: the training / model parity tests under the non-default switches (fallback kernels and stream forms must stay green)
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r4u
+mkdir -p $O
+cd $R
+run() {
+  echo "== $*" | tee -a $O/switches.txt
+  env "$@" timeout -k 10 600 python -m pytest tests/test_train_gpu.py tests/test_model_gpu.py -x -q -m gpu > $O/t.log 2>&1 || { tail -30 $O/t.log; exit 1; }
+  tail -1 $O/t.log | tee -a $O/switches.txt
+}
+run SIR_BPTT=4
+run SIR_BWD_STREAMS=0 SIR_GQ_ROLES=0
+run SIR_BWD_STREAMS=1 SIR_GQ_ROLES=3
+run SIR_BWD_STREAMS=2 SIR_BPTT_TOUCH=0
+run SIR_F16=0
+run SIR_WINO2=0 SIR_TN2=0 SIR_WGW=0
