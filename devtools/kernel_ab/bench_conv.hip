@@ -381,6 +381,17 @@ static void run_wino2(const char* name, int B, int H, int W, int reps = 60) {
             printf("  f16x3 knock-outs (one cached input): full %.1f, no DMA %.1f, no transform %.1f, no MFMA %.1f, no epilogue %.1f, only barriers+epilogue %.1f, weights once %.1f us\n",
                    koh(integral_constant<int, 32>{}), koh(integral_constant<int, 2>{}), koh(integral_constant<int, 4>{}), koh(integral_constant<int, 8>{}),
                    koh(integral_constant<int, 16>{}), koh(integral_constant<int, 14>{}), koh(integral_constant<int, 64>{}));
+            {   // fine-grained producer stamps of the f16x3 kernel (DBG = 1: complete kernel + stamps)
+                bool atf = false;
+                for (int rep = 0; rep < 3; ++rep)
+                    CK_((launch_conv_wino2<CIN, COUT, MODE, 1, 3, true>(st, &atf, dx, wph, ds, dt, o2, B, H, W, MODE == 1 ? (float2*)pl2 : st2, dzero)));
+                CK_(hipStreamSynchronize(st));
+                long long hf_[8][8];
+                CK_(hipMemcpyFromSymbol(hf_, HIP_SYMBOL(w2_dbg_fine), sizeof(hf_)));
+                printf("  f16x3 producer wave 0, steps 8..15, cycles from the step's top: DMA issued | raw patches read | V written | DMA wait over | barrier passed\n   ");
+                for (int k = 0; k < 8; ++k) printf(" [%lld %lld %lld %lld %lld]", hf_[k][1] - hf_[k][0], hf_[k][2] - hf_[k][0], hf_[k][3] - hf_[k][0], hf_[k][4] - hf_[k][0], hf_[k][5] - hf_[k][0]);
+                printf("\n");
+            }
             (void)hipFree(wph); (void)hipFree(dstat);
         }
         for (int k = 0; k < 4; ++k) (void)hipFree(dxr[k]);
@@ -403,6 +414,13 @@ static void run_wino2(const char* name, int B, int H, int W, int reps = 60) {
         }
         long long hs_[2][32];
         CK_(hipMemcpyFromSymbol(hs_, HIP_SYMBOL(w2_dbg_stamps), sizeof(hs_)));
+        {
+            long long hf_[8][8];
+            CK_(hipMemcpyFromSymbol(hf_, HIP_SYMBOL(w2_dbg_fine), sizeof(hf_)));
+            printf("  producer wave 0, steps 8..15, cycles from the step's top: DMA issued | raw patches read | V written | DMA wait over | barrier passed\n   ");
+            for (int k = 0; k < 8; ++k) printf(" [%lld %lld %lld %lld %lld]", hf_[k][1] - hf_[k][0], hf_[k][2] - hf_[k][0], hf_[k][3] - hf_[k][0], hf_[k][4] - hf_[k][0], hf_[k][5] - hf_[k][0]);
+            printf("\n");
+        }
         for (int g = 0; g < 2; ++g) {
             printf("  stamps group %c:", g ? 'B' : 'A');
             for (int k = 0; k < 2 * (2 * (CIN / 16) + 1) + 5 && k < 32; ++k) printf(" %lld", hs_[g][k] - hs_[0][0]);

@@ -58,6 +58,30 @@ constexpr int w2_lds_bytes(bool f16) { return f16 ? 2 * 2 * W2_PLB + W2_NRAW * W
 constexpr int W2_THREADS = 768;                             // 4 producer waves + 8 consumer waves
 constexpr int W2_PPW = (W2_RAW_PIECES + 3) / 4;             // DMA pieces per wave of group B
 
+// Exact unsigned division by a launch-time constant (the round-up method: q = (t + ((n - t) >> 1)) >> sh with t = mulhi(m, n); a shift for
+// powers of two).  A hardware-free 32-bit division costs ~25 vector instructions on this ISA; the producers' per-task address set-up held ten
+// of them -- ~1000 of the ~8000 cycles of a two-chunk task on the kernel's critical waves (fine-grained stamps in
+// profiles/r04/bench_conv_wino2_f16x3.txt).
+struct W2Div { unsigned m; int sh; int pow2; unsigned d; };
+static inline W2Div w2_div_make(unsigned d) {
+    W2Div r{0u, 0, 0, d};
+    if ((d & (d - 1)) == 0) { r.pow2 = 1; while ((1u << r.sh) < d) ++r.sh; return r; }
+    int l = 0;
+    while ((1ull << l) < d) ++l;                             // ceil(log2 d)
+    r.m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+    r.sh = l - 1;
+    return r;
+}
+__device__ __forceinline__ int w2_div(int n, const W2Div& d) {
+    const unsigned un = (unsigned)n;
+#ifdef SIR_W2_OLDADDR                                        // A/B build only (devtools/gpu_r4ac.sh): the ISA's division sequence
+    return (int)(un / d.d);
+#endif
+    if (d.pow2) return (int)(un >> d.sh);
+    const unsigned t = __umulhi(d.m, un);
+    return (int)((t + ((un - t) >> 1)) >> d.sh);
+}
+
 struct Wino2Geo {
     int H, W;            // input = output map (pixels)
     int TW;              // tile columns per image = ceil(W / 2)
@@ -66,12 +90,14 @@ struct Wino2Geo {
     int NS;              // spatial tasks = RBN * ceil(NG / 4)
     int Hp, Wp;          // pooled map (OUT_MODE 0 / 1)
     int B;
+    W2Div dTW, d2TW, dRBN;   // divisions by TW, 2 TW, RBN (all operands are non-negative)
 };
 // false: shape outside what the kernel covers (whole 8-tile-row blocks, 32-bit element offsets) -- the caller keeps the
 // first-generation / direct kernel for it
 static inline bool wino2_geo(int B, int H, int W, int cmax, Wino2Geo* g) {
     g->B = B; g->H = H; g->W = W; g->TW = (W + 1) / 2; g->NG = B * g->TW; g->RBN = H / 16;
     g->NS = g->RBN * ((g->NG + 3) / 4); g->Hp = H / 2; g->Wp = W / 2;
+    g->dTW = w2_div_make((unsigned)g->TW); g->d2TW = w2_div_make(2u * (unsigned)g->TW); g->dRBN = w2_div_make((unsigned)(g->RBN > 0 ? g->RBN : 1));
     return H % 16 == 0 && W >= 1 && B >= 1 && (size_t)B * H * W * cmax < ((size_t)1 << 31) && (size_t)g->NG * 2 < ((size_t)1 << 30);
 }
 // statistics blocks of OUT_MODE 2: one per (workgroup, transform-row wave); `max_wg` as passed to launch_conv_wino2
@@ -103,6 +129,7 @@ __device__ __forceinline__ void w2_write64(unsigned base, uint2 v) {
 
 // DBG (devtools/kernel_ab/bench_conv.hip only): s_memtime stamps of the first producer and the first consumer wave of workgroup 0
 __device__ long long w2_dbg_stamps[2][32];
+__device__ long long w2_dbg_fine[8][8];              // producer wave 0 of workgroup 0, steps 8..15: loop top, DMA issued, raw patches read, V written, DMA wait over, barrier passed
 // Fourth structure: 12 waves per workgroup -- 4 producers (raw patches by LDS-DMA three chunks deep, B^T d B, bf16x3, V[step & 1])
 // and 8 consumers (wave (i, n): transform row i, channel slice n: 4 accumulators, weights of its 4 frequencies one chunk ahead),
 // one barrier per chunk; a task's row transform goes through the V buffer its last chunk just left (two extra barriers per task).
@@ -143,7 +170,7 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
     auto task_geo = [&](int lt, int& g0, int& ty0, int& ch, int& s) {
         s = (int)blockIdx.x + (lt / NCHO) * (int)gridDim.x;
         ch = lt % NCHO;
-        const int rb = s % RBN, cb = s / RBN;
+        const int cb = w2_div(s, geo.dRBN), rb = s - cb * RBN;
         g0 = 4 * cb; ty0 = 8 * rb;
     };
     int nst = 0;
@@ -156,13 +183,32 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
         // ================= producers ==============================================================================================
         // (their VALU stream competes with two MFMA-issuing consumer waves for the SIMD's issue port: priority to the producer)
         if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+#ifndef SIR_W2_CLAMP
+        // MODE.FP16_OVFL = 1 for the producer waves: a conversion to fp16 that overflows gives +-65504 instead of infinity, which is what
+        // the split's two v_med3 clamps per pair were for (32 of the ~170 vector instructions per row pair and step)
+        if (F16) __builtin_amdgcn_s_setreg((1 /* HW_REG_MODE */) | (23 << 6) | (0 << 11), 1);
+#endif
         const int wg = wv;
         // wave wg = (row pair tR of the transform, 8-channel half tH); lane = (tile tm, 4-channel group tP1)
         const int tR = wg >> 1, tH = wg & 1, tm = lane >> 1, tP1 = lane & 1;
         const int tty = tm & 7, ttx = tm >> 3, tpart = 2 * tH + tP1;
         // DMA source of this lane's pieces for a task: element offset into x, or ~0u = the zero page (rows above / below the image,
         // the pad column of an odd-width map, tile columns past the batch: the transform then needs no selects for them)
+        // (the task-independent part of a piece's address -- raw row, column, channel group, "hole" positions of the padded image -- is computed
+        // once; per task a piece then costs a clamp, one magic-number division and the bounds test instead of ~60 instructions)
+        int pre_lr[W2_PPW], pre_lc[W2_PPW], pre_part[W2_PPW];
+#pragma unroll
+        for (int ii = 0; ii < W2_PPW; ++ii) {
+            const int slot = 64 * (wg + 4 * ii) + lane, pos = slot >> 2, sp = slot & 3;
+            const int lr = pos / W2_RS;
+            const int lc = pos - lr * W2_RS - ((lr >> 1) & 1);
+            const bool hole = lr > 17 || lc < 0 || lc > 9;
+            pre_lr[ii] = hole ? (1 << 20) : lr;                           // a hole fails the row test of every task
+            pre_lc[ii] = lc;
+            pre_part[ii] = (sp ^ (((lr >> 2) & 1) << 1)) * 4;
+        }
         auto raw_offsets = [&](int g0, int ty0, unsigned (&off)[W2_PPW]) {
+#ifdef SIR_W2_OLDADDR                                        // A/B build only (devtools/gpu_r4ac.sh): everything recomputed per task, the ISA's division
 #pragma unroll
             for (int ii = 0; ii < W2_PPW; ++ii) {
                 const int slot = 64 * (wg + 4 * ii) + lane, pos = slot >> 2, sp = slot & 3;
@@ -176,6 +222,17 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                 const int bb = Pc / (2 * TW), px = Pc - bb * 2 * TW;
                 const bool ok = !hole && gy >= 0 && gy < H && P >= 0 && P < 2 * NG && px < W;
                 off[ii] = ok ? (unsigned)(((bb * H + gy) * W + px) * CIN + part * 4) : ~0u;
+            }
+            return;
+#endif
+#pragma unroll
+            for (int ii = 0; ii < W2_PPW; ++ii) {
+                const int gy = 2 * ty0 - 1 + pre_lr[ii];
+                const int P = 2 * g0 - 1 + pre_lc[ii];
+                const int Pc = min(max(P, 0), 2 * NG - 1);
+                const int bb = w2_div(Pc, geo.d2TW), px = Pc - bb * 2 * TW;
+                const bool ok = gy >= 0 && gy < H && P >= 0 && P < 2 * NG && px < W;
+                off[ii] = ok ? (unsigned)(((bb * H + gy) * W + px) * CIN + pre_part[ii]) : ~0u;
             }
         };
         const int wg_u = __builtin_amdgcn_readfirstlane(wg);
@@ -212,17 +269,22 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         w2_barrier();                                                   // raw chunks 0 and 1 have landed
         bool edge = false, z0 = false, z3 = false;                      // the task holds an image boundary column; this thread's tile sits at one
+        auto fine = [&](int s_, int k_) {
+            if (DBG && blockIdx.x == 0 && lane == 0 && wv == 0 && s_ >= 8 && s_ < 16) w2_dbg_fine[s_ - 8][k_] = __builtin_amdgcn_s_memtime();
+        };
 #pragma unroll 1
         for (int s = 0; s <= nsteps; ++s) {
             stamp();
+            fine(s, 0);
             if (s < nsteps) {
                 if (!(DBG & 2)) issue_chunk(s + 2);                     // into the slot chunk s - 1 left (its reads ended before the last barrier)
+                fine(s, 1);
                 if (s % NCH == 0) {                                     // first chunk of a task: where are its image boundaries
                     int cg0, cty0, cch, cs;
                     task_geo(s / NCH, cg0, cty0, cch, cs);
-                    const int t0 = cg0 % TW;                            // tile column of the task's first column inside its image
+                    const int t0 = cg0 - w2_div(cg0, geo.dTW) * TW;     // tile column of the task's first column inside its image
                     edge = t0 == 0 || t0 + 3 >= TW - 1;
-                    const int txx = (t0 + ttx) % TW;
+                    const int txx = (t0 + ttx) - w2_div(t0 + ttx, geo.dTW) * TW;
                     z0 = txx == 0; z3 = txx == TW - 1;
                 }
                 const unsigned rb = raw_a + (s % W2_NRAW) * W2_RAW_BYTES, vd = v_a + (s & 1) * VB;
@@ -231,6 +293,7 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
 #pragma unroll
                 for (int rr = 0; rr < 3; ++rr) w2_read_row(rb + ra_rel[rr], q[rr][0], q[rr][1], q[rr][2], q[rr][3]);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                fine(s, 2);
                 if (edge) {                                             // (one task in ~12: the halo column belongs to the neighbouring image)
                     // a real branch (the asm keeps hipcc from turning it into 24 selects on the common path).  SELECT zero, do not
                     // multiply by it: the halo column was loaded from the neighbouring clip, and 0 * Inf / NaN of a corrupt
@@ -258,8 +321,13 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                             const unsigned d = vd + (4 * il + j) * 1024;
                             if constexpr (F16) {
                                 uint2 sh, sl;
+#ifdef SIR_W2_CLAMP                                          // A/B build only: the split's own clamps (v_med3 per value)
                                 split2h_pair(V[j].x, V[j].y, sh.x, sl.x);
                                 split2h_pair(V[j].z, V[j].w, sh.y, sl.y);
+#else
+                                split2h_pair_ovfl(V[j].x, V[j].y, sh.x, sl.x);
+                                split2h_pair_ovfl(V[j].z, V[j].w, sh.y, sl.y);
+#endif
                                 w2_write64<0>(d, sh);
                                 w2_write64<W2_PLB>(d, sl);
                             } else {
@@ -275,6 +343,8 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                 };
                 if (tR == 0) rows(std::integral_constant<int, 0>{});
                 else rows(std::integral_constant<int, 1>{});
+                if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                fine(s, 3);
                 }
                 // chunk s + 1 (issued a step ago) must have landed before the barrier; the pieces of chunk s + 2, just issued, may still fly
                 // (a wave issues 3 or 4 pieces per chunk: allowing its 3 newest operations to be outstanding is safe for both)
@@ -282,8 +352,10 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             stamp();
+            fine(s, 4);
             if (!F16 && s >= 1 && (s - 1) % NCH == NCH - 1) { w2_barrier(); w2_barrier(); }     // bf16x6: the consumers' row-transform exchange (barriers A, B)
             w2_barrier();
+            fine(s, 5);
         }
         return;
     }
@@ -444,7 +516,7 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                 if (OUT_MODE <= 1) { sc_ = scale[co] * DESC; sh_ = shift[co]; }
                 {
                     const int gc = g0 + mi;
-                    const int img = gc / TW, tx = gc - img * TW;
+                    const int img = w2_div(gc, geo.dTW), tx = gc - img * TW;
                     const bool tvalid = gc < NG;
                     if (OUT_MODE <= 1) {
                         float pooled[4];

@@ -22,6 +22,16 @@ __device__ __forceinline__ void split2h_pair(float a, float b, unsigned& h, unsi
     h = __builtin_bit_cast(unsigned, hi);
     l = __builtin_bit_cast(unsigned, lo);
 }
+// the same without the clamps, for waves that run with MODE.FP16_OVFL = 1 (an overflowing conversion then saturates at +-65504 by itself)
+__device__ __forceinline__ void split2h_pair_ovfl(float a, float b, unsigned& h, unsigned& l) {
+    sir_f32x2 v = {a, b};
+    const sir_f16x2 hi = __builtin_convertvector(v, sir_f16x2);
+    v -= __builtin_convertvector(hi, sir_f32x2);
+    v *= H3_LO_SCALE;
+    const sir_f16x2 lo = __builtin_convertvector(v, sir_f16x2);
+    h = __builtin_bit_cast(unsigned, hi);
+    l = __builtin_bit_cast(unsigned, lo);
+}
 __device__ __forceinline__ void split2h_quad(const float4& v, uint2& h, uint2& l) {
     split2h_pair(v.x, v.y, h.x, l.x);
     split2h_pair(v.z, v.w, h.y, l.y);
