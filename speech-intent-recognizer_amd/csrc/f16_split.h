@@ -32,6 +32,12 @@ __device__ __forceinline__ void split2h_pair_ovfl(float a, float b, unsigned& h,
     h = __builtin_bit_cast(unsigned, hi);
     l = __builtin_bit_cast(unsigned, lo);
 }
+__device__ __forceinline__ void split2h_quad_ovfl(const float4& v, uint2& h, uint2& l) {
+    split2h_pair_ovfl(v.x, v.y, h.x, l.x);
+    split2h_pair_ovfl(v.z, v.w, h.y, l.y);
+}
+// MODE.FP16_OVFL = 1 for the calling wave (hwreg id 1 = MODE, bit 23): fp16 results that overflow saturate at +-65504 instead of becoming infinity
+__device__ __forceinline__ void sir_fp16_ovfl_on() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
 __device__ __forceinline__ void split2h_quad(const float4& v, uint2& h, uint2& l) {
     split2h_pair(v.x, v.y, h.x, l.x);
     split2h_pair(v.z, v.w, h.y, l.y);

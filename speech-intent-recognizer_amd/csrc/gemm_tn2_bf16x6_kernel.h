@@ -50,6 +50,14 @@ __device__ __forceinline__ void tn2_split_b(const float4& v, uint2& hh, uint2& l
     pair(v.x, v.y, hh.x, ll.x);
     pair(v.z, v.w, hh.y, ll.y);
 }
+// the same for waves running with MODE.FP16_OVFL = 1: no clamps -- a B value beyond the range saturates in the conversion, and its hi 2^11 in the
+// consumers' v_pk_mul_f16 (they run in the same mode), instead of being clamped to 31.98 here: finite either way, one v_med3 per value less
+template <int SCALE_LOG2 = -4>
+__device__ __forceinline__ void tn2_split_b_ovfl(const float4& v, uint2& hh, uint2& ll) {
+    constexpr float SC = SCALE_LOG2 >= 0 ? (float)(1 << (SCALE_LOG2 >= 0 ? SCALE_LOG2 : 0)) : 1.0f / (float)(1 << (SCALE_LOG2 < 0 ? -SCALE_LOG2 : 0));
+    split2h_pair_ovfl(v.x * SC, v.y * SC, hh.x, ll.x);
+    split2h_pair_ovfl(v.z * SC, v.w * SC, hh.y, ll.y);
+}
 // fragment of Bh -> fragment of Bh 2^11 (exact: |Bh| < 32)
 __device__ __forceinline__ bf16x8 tn2_hi2(const bf16x8& bh) {
     return __builtin_bit_cast(bf16x8, __builtin_bit_cast(f16x8, bh) * (_Float16)2048.0f);
@@ -92,6 +100,14 @@ __global__ __launch_bounds__(TN2_THREADS, TN2_THREADS / 256) void gemm_tn2_bf16x
     const int nst = (k_end - k_begin + TN_BK - 1) / TN_BK;     // stages of this workgroup
     const int npair = nst / 2 + 1;                            // steps 0 .. nst, rounded up to pairs: 2 * npair barriers in both roles
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // fp16 overflow mode + unclamped splits for the weight-gradient form only (dW 77 -> 74 / 114 -> 109 us; the dX form measured 1.5-2 us SLOWER
+    // with it and keeps the clamps: profiles/r04/ab_fp16_ovfl.txt)
+#ifdef SIR_W2_CLAMP
+    constexpr bool OVFL = false;
+#else
+    constexpr bool OVFL = F16 && A_KM;
+#endif
+    if (OVFL) sir_fp16_ovfl_on();                            // producers: unclamped splits; consumers: Bh 2^11 saturates instead of overflowing
 
     if (wv < TN2_NPW) {
         // ================= producers ==============================================================================================
@@ -165,7 +181,8 @@ __global__ __launch_bounds__(TN2_THREADS, TN2_THREADS / 256) void gemm_tn2_bf16x
                                         : AT + (size_t)(it >> 3) * TN_ROWB + (it & 7) * 8;
                 if constexpr (F16) {
                     uint2 hh, ll;
-                    split2h_quad(pa[q], hh, ll);
+                    if constexpr (OVFL) split2h_quad_ovfl(pa[q], hh, ll);
+                    else split2h_quad(pa[q], hh, ll);
                     *reinterpret_cast<uint2*>(d) = hh;
                     *reinterpret_cast<uint2*>(d + APLANE) = ll;
                 } else {
@@ -182,7 +199,8 @@ __global__ __launch_bounds__(TN2_THREADS, TN2_THREADS / 256) void gemm_tn2_bf16x
                 unsigned char* d = BT + tn_kmaj_off<BXW>(it >> 6, 8 * (it & 63));
                 if constexpr (F16) {
                     uint2 hh, ll;
-                    tn2_split_b(pb[q], hh, ll);                        // (Bh, Bl') of B / 16
+                    if constexpr (OVFL) tn2_split_b_ovfl(pb[q], hh, ll);   // (Bh, Bl') of B / 16
+                    else tn2_split_b(pb[q], hh, ll);
                     *reinterpret_cast<uint2*>(d) = hh;
                     *reinterpret_cast<uint2*>(d + BPLANE) = ll;
                 } else {

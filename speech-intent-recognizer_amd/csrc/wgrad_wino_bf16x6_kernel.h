@@ -74,6 +74,9 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
     static_assert(TPS * PQ == (KPW == 1 ? 512 : 256) && TPS * VQ * KPW == 256, "item counts");
     extern __shared__ __attribute__((aligned(16))) unsigned char wgl[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifndef SIR_W2_CLAMP
+    if (F16) sir_fp16_ovfl_on();                             // producers: unclamped splits; consumers: Vh 2^11 saturates instead of overflowing
+#endif
     const int TH = H >> 1, TW = (W + 1) >> 1;
     const int ntiles = B * TH * TW, nstages = (ntiles + TPS - 1) / TPS;
     // blockIdx -> (strip, group of rows): the groups of a strip on one XCD (workgroup L runs on XCD L % 8) when the strips come in eights
@@ -152,8 +155,13 @@ __global__ __launch_bounds__(WGW_THREADS, WGW_THREADS / 256) void conv_wgrad_win
         auto put = [&](unsigned char* img, int plane, const float4& v) {           // img: the item's address in a frequency's first plane
             uint2 hh, mm, ll;
             if constexpr (F16) {
+#ifdef SIR_W2_CLAMP
                 if (plane == PPLANE) split2h_quad(v, hh, ll);                        // P (gradient side): (Ph, Pl')
                 else tn2_split_b<WGW_VS_LOG2>(v, hh, ll);                            // V: (Vh, Vl') of V / 32
+#else                                                        // (the kernel runs with MODE.FP16_OVFL = 1: no clamps, see tn2_split_b_ovfl)
+                if (plane == PPLANE) split2h_quad_ovfl(v, hh, ll);
+                else tn2_split_b_ovfl<WGW_VS_LOG2>(v, hh, ll);
+#endif
                 *reinterpret_cast<uint2*>(img) = hh;
                 *reinterpret_cast<uint2*>(img + plane) = ll;
                 return;
