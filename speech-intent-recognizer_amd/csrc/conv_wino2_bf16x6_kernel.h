@@ -173,6 +173,82 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
         const int cb = w2_div(s, geo.dRBN), rb = s - cb * RBN;
         g0 = 4 * cb; ty0 = 8 * rb;
     };
+    // ---- raw-patch DMA: WHO issues it ------------------------------------------------------------------------------------------
+    // The four producer waves (piece k = wave + 4 i, counted vmcnt waits in their loop) -- except in the F16 form of a 32-channel layer (the
+    // conv2 data gradient), where the four consumer waves of the missing second channel slice have nothing to do but keep the barriers: they take
+    // the DMA over, on the producers' own schedule (chunk s + 2 at the top of step s, landed by the end of step s + 1).  Stamps inside a producer's
+    // step put the issue of its 3-4 LDS-DMA pieces at ~620 of ~3500 cycles (155 per piece) on the kernel's critical waves.  (Handing the pieces to
+    // the WORKING consumers of the 64-channel forms was measured and lost 10 %: behind their MFMAs a chunk has one step instead of two to land,
+    // and the in-order return puts it in front of their weight fragments -- profiles/r04/bench_conv_wino2_f16x3.txt.)
+#ifdef SIR_W2_PRODDMA                                        // A/B build only (devtools/gpu_r4af.sh)
+    constexpr bool IDLE_DMA = false;
+#else
+    constexpr bool IDLE_DMA = F16 && COUT < 64;
+#endif
+    constexpr int D_STRIDE = 4, D_PPW = (W2_RAW_PIECES + D_STRIDE - 1) / D_STRIDE;
+    const int d_stride = D_STRIDE;
+    const int d_rank = producer ? wv : ((wv - 4) >> 1);               // (the idle waves are 5, 7, 9, 11)
+    // (the task-independent part of a piece's address -- raw row, column, channel group, "hole" positions of the padded image -- is computed
+    // once; per task a piece then costs a clamp, one magic-number division and the bounds test instead of ~60 instructions)
+    int pre_lr[D_PPW], pre_lc[D_PPW], pre_part[D_PPW];
+#pragma unroll
+    for (int ii = 0; ii < D_PPW; ++ii) {
+        const int slot = 64 * (d_rank + d_stride * ii) + lane, pos = slot >> 2, sp = slot & 3;
+        const int lr = pos / W2_RS;
+        const int lc = pos - lr * W2_RS - ((lr >> 1) & 1);
+        const bool hole = lr > 17 || lc < 0 || lc > 9;
+        pre_lr[ii] = hole ? (1 << 20) : lr;                           // a hole fails the row test of every task
+        pre_lc[ii] = lc;
+        pre_part[ii] = (sp ^ (((lr >> 2) & 1) << 1)) * 4;
+    }
+    auto raw_offsets = [&](int g0, int ty0, unsigned (&off)[D_PPW]) {
+#ifdef SIR_W2_OLDADDR                                        // A/B build only (devtools/gpu_r4ac.sh): everything recomputed per task, the ISA's division
+#pragma unroll
+        for (int ii = 0; ii < D_PPW; ++ii) {
+            const int slot = 64 * (d_rank + d_stride * ii) + lane, pos = slot >> 2, sp = slot & 3;
+            int lr = pos / W2_RS;
+            int lc = pos - lr * W2_RS - ((lr >> 1) & 1);
+            const bool hole = lr > 17 || lc < 0 || lc > 9;
+            const int part = sp ^ (((lr >> 2) & 1) << 1);
+            const int gy = 2 * ty0 - 1 + lr;
+            const int P = 2 * g0 - 1 + lc;
+            const int Pc = min(max(P, 0), 2 * NG - 1);
+            const int bb = Pc / (2 * TW), px = Pc - bb * 2 * TW;
+            const bool ok = !hole && gy >= 0 && gy < H && P >= 0 && P < 2 * NG && px < W;
+            off[ii] = ok ? (unsigned)(((bb * H + gy) * W + px) * CIN + part * 4) : ~0u;
+        }
+        return;
+#endif
+#pragma unroll
+        for (int ii = 0; ii < D_PPW; ++ii) {
+            const int gy = 2 * ty0 - 1 + pre_lr[ii];
+            const int P = 2 * g0 - 1 + pre_lc[ii];
+            const int Pc = min(max(P, 0), 2 * NG - 1);
+            const int bb = w2_div(Pc, geo.d2TW), px = Pc - bb * 2 * TW;
+            const bool ok = gy >= 0 && gy < H && P >= 0 && P < 2 * NG && px < W;
+            off[ii] = ok ? (unsigned)(((bb * H + gy) * W + px) * CIN + pre_part[ii]) : ~0u;
+        }
+    };
+        auto raw_issue = [&](const unsigned (&off)[D_PPW], int c, int slot_buf) {
+#pragma unroll
+        for (int ii = 0; ii < D_PPW; ++ii) {
+            const int k = d_rank + d_stride * ii;
+            if (k < W2_RAW_PIECES) {
+                const float* src = off[ii] == ~0u ? zeros : x + off[ii];
+                __builtin_amdgcn_global_load_lds((sir_gptr_t)(src + c * 16), (sir_lptr_t)(rawbuf + slot_buf * W2_RAW_BYTES + k * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // chunk q (global index over this workgroup's tasks) -> issue its pieces into ring slot q % 3
+    int ig0, ity0, ich, is_;
+    unsigned roff[D_PPW];
+    int roff_task = -1;
+    auto issue_chunk = [&](int q) {
+        if (q >= nsteps) return;
+        const int lt = q / NCH, c = q - lt * NCH;
+        if (lt != roff_task) { task_geo(lt, ig0, ity0, ich, is_); raw_offsets(ig0, ity0, roff); roff_task = lt; }
+        raw_issue(roff, c, q % W2_NRAW);
+    };
     int nst = 0;
     auto stamp = [&]() {
         if (DBG && blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 4) && nst < 32) w2_dbg_stamps[producer ? 0 : 1][nst] = __builtin_amdgcn_s_memtime();
@@ -194,68 +270,6 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
         const int tty = tm & 7, ttx = tm >> 3, tpart = 2 * tH + tP1;
         // DMA source of this lane's pieces for a task: element offset into x, or ~0u = the zero page (rows above / below the image,
         // the pad column of an odd-width map, tile columns past the batch: the transform then needs no selects for them)
-        // (the task-independent part of a piece's address -- raw row, column, channel group, "hole" positions of the padded image -- is computed
-        // once; per task a piece then costs a clamp, one magic-number division and the bounds test instead of ~60 instructions)
-        int pre_lr[W2_PPW], pre_lc[W2_PPW], pre_part[W2_PPW];
-#pragma unroll
-        for (int ii = 0; ii < W2_PPW; ++ii) {
-            const int slot = 64 * (wg + 4 * ii) + lane, pos = slot >> 2, sp = slot & 3;
-            const int lr = pos / W2_RS;
-            const int lc = pos - lr * W2_RS - ((lr >> 1) & 1);
-            const bool hole = lr > 17 || lc < 0 || lc > 9;
-            pre_lr[ii] = hole ? (1 << 20) : lr;                           // a hole fails the row test of every task
-            pre_lc[ii] = lc;
-            pre_part[ii] = (sp ^ (((lr >> 2) & 1) << 1)) * 4;
-        }
-        auto raw_offsets = [&](int g0, int ty0, unsigned (&off)[W2_PPW]) {
-#ifdef SIR_W2_OLDADDR                                        // A/B build only (devtools/gpu_r4ac.sh): everything recomputed per task, the ISA's division
-#pragma unroll
-            for (int ii = 0; ii < W2_PPW; ++ii) {
-                const int slot = 64 * (wg + 4 * ii) + lane, pos = slot >> 2, sp = slot & 3;
-                int lr = pos / W2_RS;
-                int lc = pos - lr * W2_RS - ((lr >> 1) & 1);
-                const bool hole = lr > 17 || lc < 0 || lc > 9;
-                const int part = sp ^ (((lr >> 2) & 1) << 1);
-                const int gy = 2 * ty0 - 1 + lr;
-                const int P = 2 * g0 - 1 + lc;
-                const int Pc = min(max(P, 0), 2 * NG - 1);
-                const int bb = Pc / (2 * TW), px = Pc - bb * 2 * TW;
-                const bool ok = !hole && gy >= 0 && gy < H && P >= 0 && P < 2 * NG && px < W;
-                off[ii] = ok ? (unsigned)(((bb * H + gy) * W + px) * CIN + part * 4) : ~0u;
-            }
-            return;
-#endif
-#pragma unroll
-            for (int ii = 0; ii < W2_PPW; ++ii) {
-                const int gy = 2 * ty0 - 1 + pre_lr[ii];
-                const int P = 2 * g0 - 1 + pre_lc[ii];
-                const int Pc = min(max(P, 0), 2 * NG - 1);
-                const int bb = w2_div(Pc, geo.d2TW), px = Pc - bb * 2 * TW;
-                const bool ok = gy >= 0 && gy < H && P >= 0 && P < 2 * NG && px < W;
-                off[ii] = ok ? (unsigned)(((bb * H + gy) * W + px) * CIN + pre_part[ii]) : ~0u;
-            }
-        };
-        const int wg_u = __builtin_amdgcn_readfirstlane(wg);
-        auto raw_issue = [&](const unsigned (&off)[W2_PPW], int c, int slot_buf) {
-#pragma unroll
-            for (int ii = 0; ii < W2_PPW; ++ii) {
-                const int k = wg_u + 4 * ii;
-                if (k < W2_RAW_PIECES) {
-                    const float* src = off[ii] == ~0u ? zeros : x + off[ii];
-                    __builtin_amdgcn_global_load_lds((sir_gptr_t)(src + c * 16), (sir_lptr_t)(rawbuf + slot_buf * W2_RAW_BYTES + k * 1024), 16, 0, 0);
-                }
-            }
-        };
-        // chunk q (global index over this workgroup's tasks) -> issue its pieces into ring slot q % 3
-        int ig0, ity0, ich, is_;
-        unsigned roff[W2_PPW];
-        int roff_task = -1;
-        auto issue_chunk = [&](int q) {
-            if (q >= nsteps) return;
-            const int lt = q / NCH, c = q - lt * NCH;
-            if (lt != roff_task) { task_geo(lt, ig0, ity0, ich, is_); raw_offsets(ig0, ity0, roff); roff_task = lt; }
-            raw_issue(roff, c, q % W2_NRAW);
-        };
         // loop-invariant LDS offsets of this thread: patch pixel (row rr, j = 0) inside a raw slot, its V destination inside a V buffer
         unsigned ra_rel[3];
 #pragma unroll
@@ -264,9 +278,11 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
             ra_rel[rr] = (unsigned)((lr * W2_RS + 2 * ttx + ((lr >> 1) & 1)) * 64 + ((tpart ^ (((lr >> 2) & 1) << 1)) * 16));
         }
         const unsigned raw_a = (unsigned)(uintptr_t)rawbuf, v_a = (unsigned)(uintptr_t)vbuf + (8 * tR) * 1024 + tH * 512 + tm * 16 + tP1 * 8;
-        issue_chunk(0);
-        issue_chunk(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!IDLE_DMA) {
+            issue_chunk(0);
+            issue_chunk(1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         w2_barrier();                                                   // raw chunks 0 and 1 have landed
         bool edge = false, z0 = false, z3 = false;                      // the task holds an image boundary column; this thread's tile sits at one
         auto fine = [&](int s_, int k_) {
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
             stamp();
             fine(s, 0);
             if (s < nsteps) {
-                if (!(DBG & 2)) issue_chunk(s + 2);                     // into the slot chunk s - 1 left (its reads ended before the last barrier)
+                if (!IDLE_DMA && !(DBG & 2)) issue_chunk(s + 2);        // into the slot chunk s - 1 left (its reads ended before the last barrier)
                 fine(s, 1);
                 if (s % NCH == 0) {                                     // first chunk of a task: where are its image boundaries
                     int cg0, cty0, cch, cs;
@@ -348,8 +364,10 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
                 }
                 // chunk s + 1 (issued a step ago) must have landed before the barrier; the pieces of chunk s + 2, just issued, may still fly
                 // (a wave issues 3 or 4 pieces per chunk: allowing its 3 newest operations to be outstanding is safe for both)
-                if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W2_RAW_PIECES / 4) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!IDLE_DMA) {
+                    if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W2_RAW_PIECES / 4) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
             }
             stamp();
             fine(s, 4);
@@ -363,7 +381,23 @@ __global__ __launch_bounds__(W2_THREADS, 3) void conv3x3_wino2_bf16x6_kernel(
     // ================= consumers ==================================================================================================
     // wave (n = cw & 1, i = cw >> 1): channel slice 32 n.., transform row i (frequencies 4 i .. 4 i + 3, 4 accumulators)
     const int cw = wv - 4, mn = cw & 1, mi = cw >> 1, m = lane & 31, h = lane >> 5;
-    if (COUT < 64 && mn == 1) {                                         // a 32-channel layer has no second slice: join the barriers, nothing else
+    if (COUT < 64 && mn == 1) {                                         // a 32-channel layer has no second slice: join the barriers --
+        if (IDLE_DMA) {                                                 // -- and (F16) feed the raw-patch ring in the producers' stead
+            if (!(DBG & 2)) { issue_chunk(0); issue_chunk(1); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            w2_barrier();                                               // raw chunks 0 and 1 have landed
+#pragma unroll 1
+            for (int s = 0; s <= nsteps; ++s) {
+                if (s < nsteps) {
+                    if (!(DBG & 2)) issue_chunk(s + 2);                 // into the slot chunk s - 1 left (its reads ended before the last barrier)
+                    // chunk s + 1 (issued a step ago) must have landed before the barrier; the 3 or 4 pieces just issued may still fly
+                    if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W2_RAW_PIECES / 4) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                w2_barrier();
+            }
+            return;
+        }
         w2_barrier();
         w2_barrier();
         for (int lt = 0; lt < ntask; ++lt)
