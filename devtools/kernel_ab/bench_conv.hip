@@ -14,6 +14,7 @@
 #include "legacy_kernels.h"
 #include "../../speech-intent-recognizer_amd/csrc/conv_wino_bf16x6_kernel.h"
 #include "../../speech-intent-recognizer_amd/csrc/conv_wino2_bf16x6_kernel.h"
+#include "conv_direct_f16x3_kernel.h"
 
 #define CK_(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -432,7 +433,113 @@ static void run_wino2(const char* name, int B, int H, int W, int reps = 60) {
     fflush(stdout);
 }
 
+// Round 4 experiment: the DIRECT convolution on the f16x3 arithmetic (conv_direct_f16x3_kernel.h: NT x MT register tile per wave) against the
+// direct bf16x6 kernel (results) -- what a convolution without the Winograd input transform costs on the fp16 pipe.
+template <int CIN, int COUT, int PR, int PC, int MODE, bool DGRAD, int NT, int MINB, int RPR, int RPC>
+static void run_direct16(const char* name, int B, int H, int W, int reps = 60) {
+    const int Hp = H / 2, Wp = W / 2;
+    const size_t nx = (size_t)B * H * W * CIN, nw = (size_t)COUT * CIN * 9;
+    const size_t nout = MODE == 2 ? (size_t)B * H * W * COUT : (size_t)B * Hp * Wp * COUT;
+    std::vector<float> hx(nx), hw(nw), hs(COUT), ht(COUT);
+    srand(13);
+    for (auto& v : hx) v = rand() / (float)RAND_MAX * 2.0f - 0.3f;
+    for (auto& v : hw) v = (rand() / (float)RAND_MAX - 0.5f) * 0.2f;
+    for (int c = 0; c < COUT; ++c) { hs[c] = 0.5f + rand() / (float)RAND_MAX; ht[c] = rand() / (float)RAND_MAX - 0.5f; }
+    float *dx, *dw, *ds, *dt, *o1, *o2;
+    unsigned short *wpb, *wph;
+    float2 *st1 = nullptr, *st2 = nullptr;
+    const dim3 gr((W + 4 * RPC - 1) / (4 * RPC), (H + 8 * RPR - 1) / (8 * RPR), B);     // the bf16x6 reference launch
+    const dim3 gd((W + 4 * PC - 1) / (4 * PC), (H + 8 * PR - 1) / (8 * PR), B);
+    CK_(hipMalloc(&dx, nx * 4)); CK_(hipMalloc(&dw, nw * 4)); CK_(hipMalloc(&ds, COUT * 4)); CK_(hipMalloc(&dt, COUT * 4));
+    CK_(hipMalloc(&o1, nout * 4)); CK_(hipMalloc(&o2, nout * 4)); CK_(hipMalloc(&wpb, nw * 6)); CK_(hipMalloc(&wph, nw * 4));
+    if (MODE == 2) { CK_(hipMalloc(&st1, (size_t)gr.x * gr.y * B * COUT * 8)); CK_(hipMalloc(&st2, (size_t)gd.x * gd.y * B * COUT * 8)); }
+    CK_(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
+    CK_(hipMemcpy(ds, hs.data(), COUT * 4, hipMemcpyHostToDevice)); CK_(hipMemcpy(dt, ht.data(), COUT * 4, hipMemcpyHostToDevice));
+    hipStream_t st; CK_(hipStreamCreate(&st));
+    const dim3 pg((CIN * 9 * COUT + 255) / 256);
+    if (DGRAD) {
+        hipLaunchKernelGGL(prep_conv_wT_bf16x3_kernel, pg, dim3(256), 0, st, (const float*)dw, wpb, COUT, CIN);
+        hipLaunchKernelGGL(prep_conv_wT_f16x3_kernel, pg, dim3(256), 0, st, (const float*)dw, wph, COUT, CIN, (unsigned int*)nullptr);
+    } else {
+        hipLaunchKernelGGL(prep_conv_w_bf16x3_kernel, pg, dim3(256), 0, st, (const float*)dw, wpb, CIN, COUT);
+        hipLaunchKernelGGL(prep_conv_w_f16x3_kernel, pg, dim3(256), 0, st, (const float*)dw, wph, CIN, COUT, (unsigned int*)nullptr);
+    }
+    CK_(hipMemsetAsync(o1, 0, nout * 4, st)); CK_(hipMemsetAsync(o2, 0, nout * 4, st));
+    constexpr size_t lds = conv_d16_lds_bytes(PR, PC);
+    auto d16 = [&](auto kn, const float* in) {
+        constexpr int KN = decltype(kn)::value;
+        static bool attr = false;
+        if (!attr && lds > 65536) {
+            CK_(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3_direct_kernel<CIN, COUT, PR, PC, MODE, NT, MINB, KN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = true;
+        }
+        hipLaunchKernelGGL((conv3x3_f16x3_direct_kernel<CIN, COUT, PR, PC, MODE, NT, MINB, KN>), gd, dim3(256), lds, st, in, (const unsigned short*)wph,
+                           (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, st2);
+    };
+    using std::integral_constant;
+    hipLaunchKernelGGL((conv3x3_bf16x6_ns_kernel<CIN, COUT, RPR, RPC, MODE, 0, 2, 1, 0>), gr, dim3(256), conv_ns_lds_bytes(RPR, RPC), st, (const float*)dx, (const unsigned short*)wpb,
+                       (const float*)ds, (const float*)dt, o1, H, W, Hp, Wp, st1);
+    d16(integral_constant<int, 0>{}, dx);
+    CK_(hipStreamSynchronize(st));
+    CK_(hipGetLastError());
+    std::vector<float> h1(nout), h2(nout);
+    CK_(hipMemcpy(h1.data(), o1, nout * 4, hipMemcpyDeviceToHost)); CK_(hipMemcpy(h2.data(), o2, nout * 4, hipMemcpyDeviceToHost));
+    double d = 0, mx = 0; size_t bad = 0;
+    for (size_t i = 0; i < nout; ++i) { const double e = fabs((double)h1[i] - h2[i]); d = fmax(d, e); mx = fmax(mx, fabs(h1[i])); bad += e > 1e-4; }
+    printf("%s: B=%d %dx%d %d->%d mode %d, tile %dx%d, NT %d, MINB %d, LDS %zu\n  max |direct bf16x6 - direct f16x3| = %.3e (max |out| %.3f), %zu elements off by > 1e-4\n", name, B, H, W, CIN, COUT,
+           MODE, 8 * PR, 4 * PC, NT, MINB, lds, d, mx, bad);
+    if (MODE == 2) {
+        const size_t n1 = (size_t)gr.x * gr.y * B, n2 = (size_t)gd.x * gd.y * B;
+        std::vector<float2> s1(n1 * COUT), s2(n2 * COUT);
+        CK_(hipMemcpy(s1.data(), st1, s1.size() * 8, hipMemcpyDeviceToHost)); CK_(hipMemcpy(s2.data(), st2, s2.size() * 8, hipMemcpyDeviceToHost));
+        double worst = 0;
+        for (int c = 0; c < COUT; ++c) {
+            double a = 0, aq = 0, b2 = 0, bq = 0;
+            for (size_t k = 0; k < n1; ++k) { a += s1[k * COUT + c].x; aq += s1[k * COUT + c].y; }
+            for (size_t k = 0; k < n2; ++k) { b2 += s2[k * COUT + c].x; bq += s2[k * COUT + c].y; }
+            worst = fmax(worst, fmax(fabs(a - b2) / fmax(1.0, fabs(a)), fabs(aq - bq) / fmax(1.0, fabs(aq))));
+        }
+        printf("  channel statistics: worst relative difference of (sum, sum of squares) = %.3e\n", worst);
+    }
+    if (B >= 64) {
+        float* dxr[4];
+        for (int k = 0; k < 4; ++k) { CK_(hipMalloc(&dxr[k], nx * 4)); CK_(hipMemcpyAsync(dxr[k], dx, nx * 4, hipMemcpyDeviceToDevice, st)); }
+        int rot = 0;
+        const double gf = 2.0 * B * H * W * (double)COUT * CIN * 9 * 1e-9;
+        const float t = time_us(st, reps, [&] { d16(integral_constant<int, 0>{}, dxr[rot++ & 3]); });
+        printf("  rotating inputs: %.1f us (%.1f TF algorithmic); knock-outs: weights once %.1f, tile staged once %.1f, no MFMA %.1f, no stores %.1f, no MFMA + no stores %.1f us\n", t, gf * 1e3 / t,
+               time_us(st, reps, [&] { d16(integral_constant<int, 1>{}, dxr[rot++ & 3]); }), time_us(st, reps, [&] { d16(integral_constant<int, 2>{}, dxr[rot++ & 3]); }),
+               time_us(st, reps, [&] { d16(integral_constant<int, 4>{}, dxr[rot++ & 3]); }), time_us(st, reps, [&] { d16(integral_constant<int, 8>{}, dxr[rot++ & 3]); }),
+               time_us(st, reps, [&] { d16(integral_constant<int, 12>{}, dxr[rot++ & 3]); }));
+        for (int k = 0; k < 4; ++k) (void)hipFree(dxr[k]);
+    }
+    (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(ds); (void)hipFree(dt); (void)hipFree(o1); (void)hipFree(o2); (void)hipFree(wpb); (void)hipFree(wph);
+    if (st1) (void)hipFree(st1); if (st2) (void)hipFree(st2);
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "direct16") {
+        const bool small = argc > 2 && std::string(argv[2]) == "small";
+        if (!small) {
+            run_direct16<64, 128, 2, 2, 1, false, 2, 2, 2, 2>("conv3 GRU layout", 256, 16, 50);
+            run_direct16<64, 128, 2, 2, 2, false, 2, 2, 2, 2>("conv3 raw", 256, 16, 50);
+            run_direct16<64, 128, 2, 2, 1, false, 1, 2, 2, 2>("conv3 GRU layout", 256, 16, 50);
+            run_direct16<64, 128, 2, 2, 1, false, 1, 3, 2, 2>("conv3 GRU layout", 256, 16, 50);
+            run_direct16<64, 128, 2, 2, 1, false, 1, 4, 2, 2>("conv3 GRU layout", 256, 16, 50);
+            run_direct16<64, 128, 2, 4, 1, false, 1, 2, 2, 2>("conv3 GRU layout", 256, 16, 50);
+            run_direct16<32, 64, 4, 2, 0, false, 2, 2, 4, 2>("conv2 pooled", 256, 32, 100);
+            run_direct16<32, 64, 4, 2, 2, false, 2, 2, 4, 2>("conv2 raw", 256, 32, 100);
+            run_direct16<128, 64, 2, 4, 2, true, 2, 2, 2, 4>("conv3 data gradient", 256, 16, 50);
+            run_direct16<64, 32, 4, 2, 2, true, 1, 2, 4, 2>("conv2 data gradient", 256, 32, 100);
+        }
+        run_direct16<64, 128, 2, 2, 1, false, 2, 2, 2, 2>("conv3 GRU layout, ragged", 3, 16, 23);
+        run_direct16<64, 128, 2, 2, 2, false, 2, 2, 2, 2>("conv3 raw, ragged", 1, 16, 15);
+        run_direct16<32, 64, 4, 2, 0, false, 2, 2, 4, 2>("conv2 pooled, ragged", 3, 32, 47);
+        run_direct16<128, 64, 2, 4, 2, true, 2, 2, 2, 4>("conv3 data gradient, ragged", 5, 16, 23);
+        run_direct16<64, 32, 4, 2, 2, true, 1, 2, 4, 2>("conv2 data gradient, ragged", 3, 32, 47);
+        return 0;
+    }
     if (argc > 1 && std::string(argv[1]) == "wino2") {
         const bool small = argc > 2 && std::string(argv[2]) == "small";
         if (!small) {
