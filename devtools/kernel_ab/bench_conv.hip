@@ -435,7 +435,7 @@ static void run_wino2(const char* name, int B, int H, int W, int reps = 60) {
 
 // Round 4 experiment: the DIRECT convolution on the f16x3 arithmetic (conv_direct_f16x3_kernel.h: NT x MT register tile per wave) against the
 // direct bf16x6 kernel (results) -- what a convolution without the Winograd input transform costs on the fp16 pipe.
-template <int CIN, int COUT, int PR, int PC, int MODE, bool DGRAD, int NT, int MINB, int RPR, int RPC>
+template <int CIN, int COUT, int PR, int PC, int MODE, bool DGRAD, int NT, int MINB, int RPR, int RPC, int WR = 3, bool AH2 = true, int NW = 4>
 static void run_direct16(const char* name, int B, int H, int W, int reps = 60) {
     const int Hp = H / 2, Wp = W / 2;
     const size_t nx = (size_t)B * H * W * CIN, nw = (size_t)COUT * CIN * 9;
@@ -470,10 +470,10 @@ static void run_direct16(const char* name, int B, int H, int W, int reps = 60) {
         constexpr int KN = decltype(kn)::value;
         static bool attr = false;
         if (!attr && lds > 65536) {
-            CK_(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3_direct_kernel<CIN, COUT, PR, PC, MODE, NT, MINB, KN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CK_(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3_direct_kernel<CIN, COUT, PR, PC, MODE, NT, MINB, KN, WR, AH2, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr = true;
         }
-        hipLaunchKernelGGL((conv3x3_f16x3_direct_kernel<CIN, COUT, PR, PC, MODE, NT, MINB, KN>), gd, dim3(256), lds, st, in, (const unsigned short*)wph,
+        hipLaunchKernelGGL((conv3x3_f16x3_direct_kernel<CIN, COUT, PR, PC, MODE, NT, MINB, KN, WR, AH2, NW>), gd, dim3(64 * NW), lds, st, in, (const unsigned short*)wph,
                            (const float*)ds, (const float*)dt, o2, H, W, Hp, Wp, st2);
     };
     using std::integral_constant;
@@ -486,8 +486,8 @@ static void run_direct16(const char* name, int B, int H, int W, int reps = 60) {
     CK_(hipMemcpy(h1.data(), o1, nout * 4, hipMemcpyDeviceToHost)); CK_(hipMemcpy(h2.data(), o2, nout * 4, hipMemcpyDeviceToHost));
     double d = 0, mx = 0; size_t bad = 0;
     for (size_t i = 0; i < nout; ++i) { const double e = fabs((double)h1[i] - h2[i]); d = fmax(d, e); mx = fmax(mx, fabs(h1[i])); bad += e > 1e-4; }
-    printf("%s: B=%d %dx%d %d->%d mode %d, tile %dx%d, NT %d, MINB %d, LDS %zu\n  max |direct bf16x6 - direct f16x3| = %.3e (max |out| %.3f), %zu elements off by > 1e-4\n", name, B, H, W, CIN, COUT,
-           MODE, 8 * PR, 4 * PC, NT, MINB, lds, d, mx, bad);
+    printf("%s: B=%d %dx%d %d->%d mode %d, tile %dx%d, NT %d, %d waves, weight ring %d, hi sets %d, LDS %zu\n  max |direct bf16x6 - direct f16x3| = %.3e (max |out| %.3f), %zu elements off by > 1e-4\n", name, B, H, W, CIN, COUT,
+           MODE, 8 * PR, 4 * PC, NT, NW, WR, AH2 ? 2 : 1, lds, d, mx, bad);
     if (MODE == 2) {
         const size_t n1 = (size_t)gr.x * gr.y * B, n2 = (size_t)gd.x * gd.y * B;
         std::vector<float2> s1(n1 * COUT), s2(n2 * COUT);
@@ -523,21 +523,20 @@ int main(int argc, char** argv) {
         const bool small = argc > 2 && std::string(argv[2]) == "small";
         if (!small) {
             run_direct16<64, 128, 2, 2, 1, false, 2, 2, 2, 2>("conv3 GRU layout", 256, 16, 50);
-            run_direct16<64, 128, 2, 2, 2, false, 2, 2, 2, 2>("conv3 raw", 256, 16, 50);
-            run_direct16<64, 128, 2, 2, 1, false, 1, 2, 2, 2>("conv3 GRU layout", 256, 16, 50);
-            run_direct16<64, 128, 2, 2, 1, false, 1, 3, 2, 2>("conv3 GRU layout", 256, 16, 50);
-            run_direct16<64, 128, 2, 2, 1, false, 1, 4, 2, 2>("conv3 GRU layout", 256, 16, 50);
-            run_direct16<64, 128, 2, 4, 1, false, 1, 2, 2, 2>("conv3 GRU layout", 256, 16, 50);
-            run_direct16<32, 64, 4, 2, 0, false, 2, 2, 4, 2>("conv2 pooled", 256, 32, 100);
-            run_direct16<32, 64, 4, 2, 2, false, 2, 2, 4, 2>("conv2 raw", 256, 32, 100);
-            run_direct16<128, 64, 2, 4, 2, true, 2, 2, 2, 4>("conv3 data gradient", 256, 16, 50);
-            run_direct16<64, 32, 4, 2, 2, true, 1, 2, 4, 2>("conv2 data gradient", 256, 32, 100);
+            run_direct16<64, 128, 2, 2, 1, false, 2, 2, 2, 2, 2, false, 2>("conv3 GRU layout", 256, 16, 50);
+            run_direct16<64, 128, 2, 2, 1, false, 2, 2, 2, 2, 3, false, 2>("conv3 GRU layout", 256, 16, 50);
+            run_direct16<64, 128, 2, 4, 1, false, 2, 2, 2, 2, 2, false, 4>("conv3 GRU layout", 256, 16, 50);
+            run_direct16<64, 128, 2, 2, 2, false, 2, 2, 2, 2, 2, false, 2>("conv3 raw", 256, 16, 50);
+            run_direct16<32, 64, 4, 2, 0, false, 2, 2, 4, 2, 2, false, 2>("conv2 pooled", 256, 32, 100);
+            run_direct16<32, 64, 4, 2, 2, false, 2, 2, 4, 2, 2, false, 2>("conv2 raw", 256, 32, 100);
+            run_direct16<128, 64, 2, 4, 2, true, 2, 2, 2, 4, 2, false, 2>("conv3 data gradient", 256, 16, 50);
+            run_direct16<64, 32, 4, 2, 2, true, 1, 2, 4, 2, 2, false, 2>("conv2 data gradient", 256, 32, 100);
         }
-        run_direct16<64, 128, 2, 2, 1, false, 2, 2, 2, 2>("conv3 GRU layout, ragged", 3, 16, 23);
-        run_direct16<64, 128, 2, 2, 2, false, 2, 2, 2, 2>("conv3 raw, ragged", 1, 16, 15);
-        run_direct16<32, 64, 4, 2, 0, false, 2, 2, 4, 2>("conv2 pooled, ragged", 3, 32, 47);
-        run_direct16<128, 64, 2, 4, 2, true, 2, 2, 2, 4>("conv3 data gradient, ragged", 5, 16, 23);
-        run_direct16<64, 32, 4, 2, 2, true, 1, 2, 4, 2>("conv2 data gradient, ragged", 3, 32, 47);
+        run_direct16<64, 128, 2, 2, 1, false, 2, 2, 2, 2, 2, false, 2>("conv3 GRU layout, ragged", 3, 16, 23);
+        run_direct16<64, 128, 2, 2, 2, false, 2, 2, 2, 2, 2, false, 2>("conv3 raw, ragged", 1, 16, 15);
+        run_direct16<32, 64, 4, 2, 0, false, 2, 2, 4, 2, 2, false, 2>("conv2 pooled, ragged", 3, 32, 47);
+        run_direct16<128, 64, 2, 4, 2, true, 2, 2, 2, 4, 2, false, 2>("conv3 data gradient, ragged", 5, 16, 23);
+        run_direct16<64, 32, 4, 2, 2, true, 1, 2, 4, 2, 2, false, 2>("conv2 data gradient, ragged", 3, 32, 47);
         return 0;
     }
     if (argc > 1 && std::string(argv[1]) == "wino2") {

@@ -15,9 +15,9 @@
 //               (4 v_pk_mul_f16 per slice).  Terms per product and accumulator: (Al', Wh), (Ah, Wl'), (Ah, Wh 2^11) -- cross terms first;
 //               the accumulators run 2^11 too large and the epilogue scales by the exact 2^-11.
 // STATUS (round 4): an EXPERIMENT of the A/B harness (bench_conv direct16), not part of libsir_hip.so.  Results equal the bf16x6 direct kernel's to
-// 1e-5 on every shape and mode, ragged ones included; timings (profiles/r04/bench_conv_direct_f16x3.txt): 102-104 us for conv3's inference form
-// where the Winograd kernel takes 84-87 -- at a 2 x 2 register tile the weight fragments cost 4 KB of L2 reads per 12 MFMAs (~1 GB per launch,
-// 26 us at the L2's rate: knock-out "weights once"), and the 4 x 2 tile that halves that needs ~270 registers at two waves per SIMD (spills).
+// 1e-5 on every shape and mode, ragged ones included; timings (profiles/r04/bench_conv_direct_f16x3.txt): 100-105 us for conv3's inference form in
+// every tiling tried (2 x 2, 4 x 1, spill-free 4 x 2 in two-wave workgroups) where the Winograd kernel takes 84-87 -- the knock-outs add up instead of
+// overlapping (two waves per SIMD, weight fragments only 1-2 taps ahead of an L2 round trip of 1-2 us).
 // OUT_MODE 0: BN (folded) + ReLU + 2x2 max-pool, NHWC; 1: the same in the GRU layout [B][Wp][COUT * Hp] (+ the f16x2 planes of the
 // following GEMM's operand when `stats` is given); 2: raw output + per-workgroup channel sums / sums of squares in `stats`.
 #pragma once
@@ -51,21 +51,23 @@ static __global__ void prep_conv_wT_f16x3_kernel(const float* __restrict__ w, un
 
 // KNOCK (timing experiments of devtools/kernel_ab/bench_conv.hip, results invalid; 0 in the product): bit 0 = weights loaded once,
 // bit 1 = tile staged once, bit 2 = no MFMAs, bit 3 = no output stores
-template <int CIN, int COUT, int PR, int PC, int OUT_MODE, int NT = 2, int MINB = 2, int KNOCK = 0>
-__global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_direct_kernel(
+// NW = waves per workgroup (4, or 2: half the pixels per workgroup with the SAME register tile -- e.g. 16x8 pixels x 128 channels as 2 waves of 4 x 2)
+template <int CIN, int COUT, int PR, int PC, int OUT_MODE, int NT = 2, int MINB = 2, int KNOCK = 0, int WR = 3, bool AH2 = true, int NW = 4>
+__global__ __launch_bounds__(64 * NW, MINB) void conv3x3_f16x3_direct_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wph, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int H, int W, int Hp, int Wp, float2* __restrict__ stats) {
-    constexpr int WN = COUT / (32 * NT), WM = 4 / WN, MT = PR * PC / WM, CK = 16, PSB = 16;
+    constexpr int BLK = 64 * NW, WN = COUT / (32 * NT), WM = NW / WN, MT = PR * PC / WM, CK = 16, PSB = 16;
+    constexpr bool HALF = MT * NT < 8;                      // big register tiles: no half-tile path (hipcc keeps the idle accumulators AND out-of-place copies)
     constexpr int TR = 8 * PR, TC = 4 * PC, TROWS = TR + 2, TCOLS = TC + 2;
     constexpr int RSB = conv_ns_row_bytes(PC), HSB = TCOLS * 16, PLANE = TROWS * RSB, TILEB = 2 * PLANE;
     constexpr int G = (CIN / 16) * 9, NCH = CIN / CK;
-    constexpr int NITEMS = TROWS * TCOLS * 4, NIT = (NITEMS + 255) / 256;
-    static_assert(COUT % (32 * NT) == 0 && WN <= 4 && 4 % WN == 0 && (PR * PC) % WM == 0 && CIN % CK == 0 && MT >= 1, "tile shape");
+    constexpr int NITEMS = TROWS * TCOLS * 4, NIT = (NITEMS + BLK - 1) / BLK;
+    static_assert(COUT % (32 * NT) == 0 && WN <= NW && NW % WN == 0 && (PR * PC) % WM == 0 && CIN % CK == 0 && MT >= 1, "tile shape");
     constexpr int SPT = (NIT + 7) / 8, T0 = 9 - (NIT + SPT - 1) / SPT;   // SPT staging items split and written per tap, over the LAST taps of a chunk
     static_assert(MT == 1 || MT % 2 == 0, "half-tile dispatch");
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     const int b = blockIdx.z, ty0 = blockIdx.y * TR, tx0 = blockIdx.x * TC;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the weight addresses below are SGPR base + one lane offset
     const int wn = wv % WN, wm = wv / WN;
     const int m = lane & 31, h = lane >> 5;
     const int pxl = (m & 1) + 2 * ((m >> 2) & 1);
@@ -83,13 +85,14 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_direct_kernel(
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
-    const uint4* wp4 = reinterpret_cast<const uint4*>(wph) + (size_t)(wn * NT * 32 + m) * 2 + h;   // + ((p * G + g) * COUT + nt * 32) * 2
+    const uint4* wp4 = reinterpret_cast<const uint4*>(wph) + (size_t)(wn * NT * 32) * 2;            // wave-uniform; + ((p * G + g) * COUT + nt * 32) * 2 + lane part
+    const int wlane = m * 2 + h;
     const float* xb = x + (size_t)b * H * W * CIN;
     auto load_w = [&](int g, uint4 (&wf)[NT][2]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) wf[nt][p] = wp4[(((size_t)p * G + g) * COUT + nt * 32) * 2];
+            for (int p = 0; p < 2; ++p) wf[nt][p] = (wp4 + (((size_t)p * G + g) * COUT + nt * 32) * 2)[wlane];
     };
 
     // staging items: (pixel, 4-channel part) -> element offset in the image (-1: zero padding), byte offset in the tile (-1: none).  16
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_direct_kernel(
     float4 pre[NIT];
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-        const int idx = tid + 256 * k;
+        const int idx = tid + BLK * k;
         const int hsel = idx / (2 * TROWS * TCOLS), rem = idx - hsel * (2 * TROWS * TCOLS);
         const int pix = rem >> 1, part = 2 * hsel + (rem & 1);
         const int tyy = pix / TCOLS, txx = pix - tyy * TCOLS;
@@ -125,9 +128,10 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_direct_kernel(
 
     // weight fragments: a ring of three taps (9 % 3 == 0: static indices across the chunk loop), fetched TWO taps (24-48 MFMAs) ahead --
     // one f16x3 tap of a 2 x 2 register tile is 384 matrix cycles, less than an L2 round trip
-    uint4 wq[3][NT][2];
+    static_assert(WR == 3 || WR == 2, "weight ring");
+    uint4 wq[3][NT][2];                                      // WR == 2: slots 0 (current) and 1 (next), copied at the end of a tap
     load_w(0, wq[0]);
-    if (G > 1) load_w(1, wq[1]);
+    if (WR == 3 && G > 1) load_w(1, wq[1]);
     stage_load(0);
 #pragma unroll
     for (int k = 0; k < NIT; ++k) stage_store_item(ldsb, k);
@@ -154,12 +158,12 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_direct_kernel(
             for (int tap = 0; tap < 9; ++tap) {
                 const int g = cc * 9 + tap;
                 if (tap == 0 && stage_next) stage_load(cc + 1);
-                if (!(KNOCK & 1) && g + 2 < G) load_w(g + 2, wq[(tap + 2) % 3]);
+                if (!(KNOCK & 1) && g + WR - 1 < G) load_w(g + WR - 1, wq[WR == 3 ? (tap + 2) % 3 : 1]);
                 f16x8 wh[NT], wl[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    wh[nt] = __builtin_bit_cast(f16x8, wq[(KNOCK & 1) ? 0 : tap % 3][nt][0]);
-                    wl[nt] = __builtin_bit_cast(f16x8, wq[(KNOCK & 1) ? 0 : tap % 3][nt][1]);
+                    wh[nt] = __builtin_bit_cast(f16x8, wq[((KNOCK & 1) || WR == 2) ? 0 : tap % 3][nt][0]);
+                    wl[nt] = __builtin_bit_cast(f16x8, wq[((KNOCK & 1) || WR == 2) ? 0 : tap % 3][nt][1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(KNOCK & 4)) {
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_direct_kernel(
                         for (int nt = 0; nt < NT; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[i], wh[nt], acc[i][nt], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (tap < 8) { rd(tap + 1, 1, alo); rd(tap + 1, 0, ahin); }   // the next tap's fragments ride behind the second and third terms
+                if (tap < 8) { rd(tap + 1, 1, alo); if (AH2) rd(tap + 1, 0, ahin); }   // the next tap's fragments ride behind the second and third terms
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(KNOCK & 4)) {
 #pragma unroll
@@ -192,13 +196,21 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_direct_kernel(
                         if ((tap - T0) * SPT + q < NIT) stage_store_item(tile_next, (tap - T0) * SPT + q);
                 }
                 if (tap < 8) {
+                    if (AH2) {
 #pragma unroll
-                    for (int i = 0; i < NP; ++i) ahi[i] = ahin[i];
+                        for (int i = 0; i < NP; ++i) ahi[i] = ahin[i];
+                    } else rd(tap + 1, 0, ahi);              // free once the third term has issued; the next tap's first term covers the latency
+                }
+                if (WR == 2 && !(KNOCK & 1) && g + 1 < G) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) wq[0][nt][p] = wq[1][nt][p];
                 }
             }
         };
-        if (2 * nvalid > MT || MT == 1) taps(std::integral_constant<int, MT>{});
-        else if (nvalid > 0) taps(std::integral_constant<int, (MT + 1) / 2>{});
+        if (2 * nvalid > MT || MT == 1 || (!HALF && nvalid > 0)) taps(std::integral_constant<int, MT>{});
+        else if (HALF && nvalid > 0) taps(std::integral_constant<int, (MT + 1) / 2>{});
         else if (stage_next) {                               // a wave without pixels still stages its share
             stage_load(cc + 1);
 #pragma unroll
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_direct_kernel(
             }
             __syncthreads();
             const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-            for (int c = tid; c < COUT; c += 256) {
+            for (int c = tid; c < COUT; c += BLK) {
                 float s = 0.0f, q = 0.0f;
 #pragma unroll
                 for (int w4 = 0; w4 < WM; ++w4) { s += lds[(w4 * COUT + c) * 2]; q += lds[(w4 * COUT + c) * 2 + 1]; }
