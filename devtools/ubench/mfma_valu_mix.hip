@@ -1,3 +1,5 @@
+// NOTE on reading the output: waves of one kind on a SIMD are served oldest-first (mfma_chain.hip), so the stamps are the rate of the FIRST-served wave of
+// each role; the printed "its SIMD: one per ..." quotients are not throughput.  s_memtime ticks are core cycles.
 // Issue-sharing probe: ONE wave per SIMD runs plain fp32 VALU work (a Winograd producer's kind of instruction stream) while TWO waves per SIMD
 // run v_mfma_f32_32x32x16_f16 in the consumers' pattern (12 MFMAs per round on four accumulators).  How much does each side lose to the other?
 //   build: hipcc -O3 --offload-arch=gfx950 mfma_valu_mix.hip -o mfma_valu_mix ; run on the GPU box
