@@ -13,6 +13,7 @@
 #include "../../speech-intent-recognizer_amd/csrc/bf16x6_kernels.h"
 #include "../../speech-intent-recognizer_amd/csrc/f16x3_kernels.h"
 #include "legacy_kernels.h"
+#include "gemm_f16x3_w4_kernel.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
 
@@ -117,6 +118,25 @@ static float time_h3(hipStream_t st, const unsigned short* Ap, const unsigned sh
     hipEventRecord(e0, st);
     for (int i = 0; i < reps; ++i)
         hipLaunchKernelGGL((gemm_nt_f16x3_kernel<NST, KNOCK>), dim3(nwg), dim3(512), h3_lds_bytes(NST), st, Ap, B0, B1, bias, bias + N, C, 2 * N, M, N, K);
+    hipEventRecord(e1, st);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1000.0f / reps;
+}
+
+template <int KNOCK, bool XT = true>
+static float time_h3w4(hipStream_t st, const unsigned short* Ap, const unsigned short* B0, const unsigned short* B1, const float* bias,
+                       float* C, int M, int N, int K, int reps) {
+    hipFuncSetAttribute((const void*)gemm_nt_f16x3_w4_kernel<KNOCK, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, h3_lds_bytes(3));
+    const int nwg = ((M + H3_BM - 1) / H3_BM) * 2 * (N / H3_BN);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i)
+        hipLaunchKernelGGL((gemm_nt_f16x3_w4_kernel<KNOCK, XT>), dim3(nwg), dim3(256), h3_lds_bytes(3), st, Ap, B0, B1, bias, bias + N, C, 2 * N, M, N, K);
+    hipEventRecord(e0, st);
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL((gemm_nt_f16x3_w4_kernel<KNOCK, XT>), dim3(nwg), dim3(256), h3_lds_bytes(3), st, Ap, B0, B1, bias, bias + N, C, 2 * N, M, N, K);
     hipEventRecord(e1, st);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -246,6 +266,16 @@ int main(int argc, char** argv) {
         const float t3 = time_h3<3, 0>(st, hA2, H0, H1, dbias, C2, M, N, K, reps);
         const double eh = errs("f16x3, 3 stages", C2, t3);
         printf("f16x3 (3 stages) vs bf16x6: %.2fx faster, rms error %.2fx\n", tb / t3, eh / eb);
+        // round 4 experiment: four fat waves (160 x 64 per wave, one 2^11-scaled accumulator per product, register double-buffered fragments)
+        CK(hipMemset(C2, 0, (size_t)M * 2 * N * 4));
+        const float t4 = time_h3w4<0>(st, hA2, H0, H1, dbias, C2, M, N, K, reps);
+        const double e4 = errs("f16x3, four 160x64 waves", C2, t4);
+        printf("four-wave form vs f16x3 (3 stages): %.2fx faster, rms error %.2fx;  knock-outs: no staging %.1f us, no MFMA %.1f us\n", t3 / t4, e4 / eh,
+               time_h3w4<1>(st, hA2, H0, H1, dbias, C2, M, N, K, reps), time_h3w4<4>(st, hA2, H0, H1, dbias, C2, M, N, K, reps));
+        CK(hipMemset(C2, 0, (size_t)M * 2 * N * 4));
+        const float t5 = time_h3w4<0, false>(st, hA2, H0, H1, dbias, C2, M, N, K, reps);
+        errs("f16x3, four waves, barrier at tile end", C2, t5);
+        printf("  its knock-outs: no staging %.1f us, no MFMA %.1f us\n", time_h3w4<1, false>(st, hA2, H0, H1, dbias, C2, M, N, K, reps), time_h3w4<4, false>(st, hA2, H0, H1, dbias, C2, M, N, K, reps));
         printf("f16x3 timing-only knock-outs (results invalid):\n");
         printf("  3 stages, no staging   %8.1f us\n", time_h3<3, 1>(st, hA2, H0, H1, dbias, C2, M, N, K, reps));
         printf("  3 stages, no MFMA      %8.1f us\n", time_h3<3, 4>(st, hA2, H0, H1, dbias, C2, M, N, K, reps));
